@@ -1,0 +1,73 @@
+"""The CPU oracle against the committed golden vectors (tests/golden/make_golden.py says where each comes from):
+the reference's own layered_rgb_blend (renderer.py:175-202), ATen grid_sample as TexturesUV uses it, and the
+reference's UV / rotation helpers (tools.py:164-231)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import orc
+from unicorn_amd import synth
+
+
+@pytest.mark.parametrize("name", ["hard", "clip", "sigmoid", "clip_s1e-2"])
+def test_layered_blend_matches_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"blend_{name}.npz"))
+    mode = orc.blend_mode(float(g["sigma"]), bool(g["clip_inside"]))
+    img = orc.layered_blend(g["colors"], g["pix_to_face"], g["dists"], float(g["sigma"]), g["background"], mode)
+    np.testing.assert_allclose(img, g["image"], atol=1e-5, rtol=0)
+    gcol, gds = orc.layered_blend_bwd(g["colors"], g["pix_to_face"], g["dists"], g["cotangent"], float(g["sigma"]),
+                                      g["background"], mode)
+    np.testing.assert_allclose(gcol, g["grad_colors"], atol=1e-5, rtol=1e-4)
+    scale = max(1.0, float(np.abs(g["grad_dists"]).max()))
+    np.testing.assert_allclose(gds, g["grad_dists"], atol=1e-5 * scale, rtol=1e-4)
+
+
+def test_uv_sampling_matches_grid_sample(golden_dir):
+    g = np.load(os.path.join(golden_dir, "uvsample.npz"))
+    maps, uv = g["maps"], g["uv"]  # (N,Ht,Wt,C), (N,P,2)
+    N, P = uv.shape[:2]
+    # one face per sample whose three UV corners are e0, e1, e2 and barycentrics chosen so that sum b_i uv_i == uv:
+    # face_uvs = [(1,0),(0,1),(0,0)], bary = (u, v, 1-u-v)
+    face_uvs = np.tile(np.array([[1, 0], [0, 1], [0, 0]], np.float32)[None], (N * P, 1, 1))
+    bary = np.stack([uv[..., 0], uv[..., 1], 1 - uv[..., 0] - uv[..., 1]], -1).reshape(N, P, 1, 1, 3)
+    p2f = np.arange(N * P, dtype=np.int64).reshape(N, P, 1, 1)
+    tex = orc.sample_textures(maps, face_uvs, p2f, bary)
+    np.testing.assert_allclose(tex.reshape(N, P, -1), g["texels"], atol=2e-6, rtol=0)
+    gm, gb = orc.sample_textures_bwd(maps, face_uvs, p2f, bary, g["cotangent"].reshape(tex.shape))
+    np.testing.assert_allclose(gm, g["grad_maps"], atol=1e-5, rtol=1e-5)
+    gb = gb.reshape(N, P, 3)
+    # d/du = gb0 (coefficient of e0) ... with b2 = 1-u-v eliminated the uv gradient is (gb0, gb1) directly since
+    # face_uvs[2] = 0 contributes nothing
+    np.testing.assert_allclose(gb[..., :2], g["grad_uv"], atol=1e-4, rtol=1e-4)
+
+
+def test_padded_fragments_sample_uv_zero(golden_dir):
+    g = np.load(os.path.join(golden_dir, "uvsample.npz"))
+    maps = g["maps"][:1]
+    p2f = np.full((1, 1, 1, 2), -1, np.int64)
+    bary = np.full((1, 1, 1, 2, 3), -1, np.float32)
+    tex = orc.sample_textures(maps, np.zeros((1, 3, 2), np.float32), p2f, bary)
+    # uv = 0 -> grid (-1,-1) -> flipped-map texel (0,0) = input row Ht-1, col 0
+    np.testing.assert_allclose(tex[0, 0, 0, 0], maps[0, -1, 0], atol=1e-7)
+
+
+def test_synth_helpers_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "helpers.npz"))
+    np.testing.assert_allclose(synth.spherical_uvs(torch.from_numpy(g["X"])).numpy(), g["uv"], atol=1e-6)
+    a = torch.from_numpy(g["angles"])
+    np.testing.assert_allclose(synth.azim_rotation(a[0]).numpy(), g["R_azim"], atol=1e-6)
+    np.testing.assert_allclose(synth.elev_rotation(a[1]).numpy(), g["R_elev"], atol=1e-6)
+    np.testing.assert_allclose(synth.roll_rotation(a[2]).numpy(), g["R_roll"], atol=1e-6)
+    np.testing.assert_allclose(synth.pose_to_R(a[0], a[1], a[2]).numpy(), g["R"], atol=1e-6)
+
+
+def test_icosphere_counts():
+    for level, (v, f) in {3: (642, 1280), 4: (2562, 5120)}.items():
+        verts, faces = synth.icosphere(level)
+        assert verts.shape == (v, 3) and faces.shape == (f, 3)
+        np.testing.assert_allclose(verts.norm(dim=1).numpy(), 1.0, atol=1e-6)
+        # outward orientation
+        a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+        assert (torch.cross(b - a, c - a, dim=1) * (a + b + c)).sum(1).min() > 0
