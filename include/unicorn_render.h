@@ -1,0 +1,120 @@
+/*
+ * unicorn_render.h -- C ABI of the MI355X (gfx950) differentiable mesh renderer.
+ *
+ * This is the drop-in boundary for the hot path behind monniert/unicorn's `Renderer`
+ * (src/model/renderer.py:25-116).  In the reference stack that path crosses into native code through the pybind11
+ * module `pytorch3d._C` (pytorch3d==0.6.2, environment.yml:21, not vendored in the reference) plus ATen's
+ * grid_sampler, and the blend runs as ~15 torch kernels (renderer.py:175-202).  Every entry point below names the
+ * reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless it says "host";
+ *   - the caller allocates everything (outputs and workspace); nothing here calls hipMalloc/hipFree or syncs;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) of the CURRENT device;
+ *   - return value 0 = success, negative = error (ur_last_error() gives the message, thread-local);
+ *   - floating point is fp32, face indices are int32 (pytorch3d uses int64; the Python layer widens on demand);
+ *   - pix_to_face holds PACKED face indices (mesh n's faces start at mesh_first_face[n]), -1 = empty slot;
+ *   - the library is stateless and thread-safe.
+ */
+#ifndef UNICORN_RENDER_H
+#define UNICORN_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UR_OK 0
+#define UR_ERR_INVALID_ARG (-1)
+#define UR_ERR_UNSUPPORTED (-2)
+#define UR_ERR_LAUNCH (-3)
+#define UR_ERR_WORKSPACE (-4)
+
+/* blend modes of layered_rgb_blend (renderer.py:186-191) */
+#define UR_BLEND_HARD 0        /* sigma == 0        : alpha = (dist <= 0)                      */
+#define UR_BLEND_CLIP_INSIDE 1 /* clip_inside=True  : alpha = exp(-max(dist, 0) / sigma)       */
+#define UR_BLEND_SIGMOID 2     /* clip_inside=False : alpha = sigmoid(-dist / sigma)           */
+
+const char* ur_last_error(void);
+int ur_abi_version(void);
+
+/* Bytes of device workspace the raster / render entry points need for `total_faces` packed faces. */
+size_t ur_workspace_bytes(int64_t total_faces);
+
+/*
+ * World -> view -> NDC of every face corner, fused with the face gather.
+ * Replaces: MeshRasterizer.transform + cameras.transform_points + verts_packed[faces_packed]
+ *           (pytorch3d, reached from renderer.py:48 with the cameras of renderer.py:59-63).
+ *   view = v @ R[n] + T[n] ; x_ndc = sx * x / z ; y_ndc = sy * y / z ; z_ndc = z_view
+ *   verts (N,V,3), faces (F,3) int32 shared topology, R (N,3,3), T (N,3) -> face_verts (N*F,3,3)
+ */
+int ur_project_faces(const float* verts, const int32_t* faces, const float* R, const float* T, float sx, float sy,
+                     int N, int V, int F, float* face_verts, void* stream);
+
+/* Backward of ur_project_faces: grad_face_verts (N*F,3,3) -> grad_verts (N,V,3), grad_R (N,3,3), grad_T (N,3).
+ * All three outputs must be zero-filled by the caller (they are accumulated with float atomics); any may be NULL. */
+int ur_project_faces_backward(const float* verts, const int32_t* faces, const float* R, const float* T, float sx,
+                              float sy, int N, int V, int F, const float* grad_face_verts, float* grad_verts,
+                              float* grad_R, float* grad_T, void* stream);
+
+/*
+ * Per-pixel top-K rasterization.
+ * Replaces: pytorch3d._C.rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh,
+ *           clipped_faces_neighbor_idx, image_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin,
+ *           perspective_correct, clip_barycentric_coords, cull_backfaces), call site renderer.py:46-49,54-57.
+ * There is no bin_size / max_faces_per_bin: binning is internal (16x16 bins -> 8x8 tiles, lists in LDS, processed
+ * in rounds) and cannot overflow.  perspective_correct must be 0 (the reference never enables it, renderer.py:47,55).
+ *   face_verts (NF,3,3) ; mesh_first_face, mesh_num_faces (N) int64 (host or device? DEVICE) ;
+ *   outputs (N,H,W,K): pix_to_face int32, zbuf, dists fp32 ; bary (N,H,W,K,3).  Any of zbuf/bary/dists may be NULL.
+ */
+int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
+                        int64_t total_faces, int H, int W, float blur_radius, int K, int perspective_correct,
+                        int clip_barycentric_coords, int cull_backfaces, int32_t* pix_to_face, float* zbuf,
+                        float* bary, float* dists, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Replaces: pytorch3d._C.rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists,
+ *           perspective_correct, clip_barycentric_coords) -> grad_face_verts (NF,3,3), reached from trainer.py:151.
+ * grad_face_verts must be zero-filled by the caller.  Any of grad_zbuf / grad_bary / grad_dists may be NULL (= zeros).
+ */
+int ur_rasterize_meshes_backward(const float* face_verts, const int32_t* pix_to_face, const float* grad_zbuf,
+                                 const float* grad_bary, const float* grad_dists, int N, int64_t total_faces, int H,
+                                 int W, int K, int perspective_correct, int clip_barycentric_coords,
+                                 float* grad_face_verts, void* stream);
+
+/*
+ * Bin assignment export (tests / debugging): which faces can touch which 8x8 pixel tile, ascending packed index.
+ * counts (N,TH,TW) int32 exact even past `cap`; lists (N,TH,TW,cap) int32, -1 padded.  TH = ceil(H/8), TW = ceil(W/8).
+ * Same scan code as ur_rasterize_meshes.  Replaces: pytorch3d._C._rasterize_meshes_coarse (bin_faces).
+ */
+int ur_tile_faces(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
+                  int64_t total_faces, int H, int W, float blur_radius, int cull_backfaces, int cap, int32_t* counts,
+                  int32_t* lists, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * UV texture sampling fused with the layered blend: fragments -> RGBA image (N,4,H,W).
+ * Replaces: LayeredShader.forward (renderer.py:159-172) = TexturesUV.sample_textures (interp_face_attrs +
+ *           grid_sample(flip_y(map), 2uv-1, bilinear, align_corners=True, 'border')) + ambient multiply (:163-164)
+ *           + layered_rgb_blend (:175-202).
+ *   maps (N,Ht,Wt,3) ; face_uvs (NF or F,3,2) with face_uvs_shared = 1 when one (F,3,2) table serves every mesh
+ *   (then mesh_first_face gives the offset to subtract) ; background host float[3] ; ambient host float[3] or NULL.
+ */
+int ur_shade_blend(const int32_t* pix_to_face, const float* bary, const float* dists, const float* maps,
+                   const float* face_uvs, int face_uvs_shared, const int64_t* mesh_first_face, int N, int H, int W,
+                   int K, int Ht, int Wt, float sigma, const float* background, const float* ambient, int mode,
+                   float* image, void* stream);
+
+/* Backward of ur_shade_blend: grad_image (N,4,H,W) -> grad_maps (N,Ht,Wt,3) [zero-filled by the caller, float
+ * atomics], grad_bary (N,H,W,K,3), grad_dists (N,H,W,K) [fully written].  grad_maps may be NULL. */
+int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face, const float* bary,
+                            const float* dists, const float* maps, const float* face_uvs, int face_uvs_shared,
+                            const int64_t* mesh_first_face, int N, int H, int W, int K, int Ht, int Wt, float sigma,
+                            const float* background, const float* ambient, int mode, float* grad_maps,
+                            float* grad_bary, float* grad_dists, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNICORN_RENDER_H */

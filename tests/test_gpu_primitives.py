@@ -1,0 +1,216 @@
+"""GPU parity of the C-ABI entry points (include/unicorn_render.h) against the CPU oracle, same seeded inputs.
+Bars (BASELINE.json north_star): pix_to_face and tile lists bit-exact; zbuf/bary/dists/images <= 1e-5 abs;
+gradients <= 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import orc
+from unicorn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+S_FOV30 = float(1.0 / np.tan(np.deg2rad(15.0)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from unicorn_amd import native as nat
+    assert torch.cuda.is_available()
+    nat.lib()
+    return nat
+
+
+def _scene_faces(N, level, seed, scale=0.6):
+    sc = synth.make_scene(N, level=level, seed=seed, scale=scale)
+    vn = orc.project_verts(sc["verts"].numpy(), sc["R"].numpy(), sc["T"].numpy(), S_FOV30)
+    faces = sc["faces"].numpy()
+    F = faces.shape[0]
+    fv = np.stack([vn[n][faces] for n in range(N)]).reshape(-1, 3, 3).astype(np.float32)
+    first = np.arange(N, dtype=np.int64) * F
+    nf = np.full(N, F, dtype=np.int64)
+    return sc, fv, first, nf
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-20))
+
+
+RASTER_CASES = [
+    # N, level, H, W, K, sigma (blur = ln(9999)*sigma ; 0 -> hard)
+    (2, 3, 64, 64, 50, 1e-4),   # BASELINE configs[1] shape (sn config), reduced batch
+    (2, 2, 24, 20, 7, 3e-4),    # ragged image, K smaller than the hit count -> top-K eviction path
+    (1, 3, 64, 64, 1, 0.0),     # configs[0]: hard raster K=1
+    (2, 1, 40, 72, 12, 1e-3),   # non-square, W > H
+    (1, 3, 128, 128, 50, 1e-4), # headline resolution
+    (1, 2, 16, 16, 100, 1e-3),  # K=100 -> 2 waves per workgroup
+    (1, 1, 8, 8, 260, 1e-3),    # K=260 -> 1 wave per workgroup
+]
+
+
+@pytest.mark.parametrize("N,level,H,W,K,sigma", RASTER_CASES)
+def test_rasterize_matches_oracle(native, N, level, H, W, K, sigma):
+    sc, fv, first, nf = _scene_faces(N, level, seed=K)
+    blur = orc.blur_radius_for(sigma)
+    clip = blur > 0
+    ref = orc.rasterize(fv, N, H, W, blur, K, clip_bary=clip)
+    out = native.rasterize_meshes(_dev(fv), _dev(first), _dev(nf), (H, W), blur, K, clip)
+    torch.cuda.synchronize()
+    p2f, zb, bar, ds = [o.cpu().numpy() for o in out]
+    assert (ref[0] >= 0).sum() > 0
+    np.testing.assert_array_equal(p2f, ref[0].astype(np.int32))           # bit-exact visibility
+    np.testing.assert_allclose(zb, ref[1], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(bar, ref[2], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(ds, ref[3], atol=1e-5, rtol=0)
+    # the kernels are built with fp contraction off and IEEE division: expect the floats to be identical too
+    assert np.array_equal(zb, ref[1]) and np.array_equal(bar, ref[2]) and np.array_equal(ds, ref[3])
+
+
+def test_rasterize_heterogeneous_meshes_and_empty_mesh(native):
+    # packed batch of meshes with different face counts, one of them empty
+    _, fa, _, _ = _scene_faces(1, 1, seed=1)
+    _, fb, _, _ = _scene_faces(1, 2, seed=2)
+    fv = np.concatenate([fa, fb])
+    first = np.array([0, len(fa), len(fa)], np.int64)
+    nf = np.array([len(fa), 0, len(fb)], np.int64)
+    H = W = 32
+    blur = orc.blur_radius_for(1e-4)
+    ref = orc.rasterize(fv, 3, H, W, blur, 6, first_idx=first, num_faces=nf)
+    out = native.rasterize_meshes(_dev(fv), _dev(first), _dev(nf), (H, W), blur, 6, True)
+    np.testing.assert_array_equal(out[0].cpu().numpy(), ref[0].astype(np.int32))
+    assert (out[0][1] == -1).all() and (out[1][1] == -1).all()
+    np.testing.assert_array_equal(out[3].cpu().numpy(), ref[3])
+
+
+def test_rasterize_culls_and_ties(native):
+    big = [[-3.0, -3.0], [3.0, -3.0], [0.0, 3.0]]
+    zs = [5.0, 2.0, 2.0, 9.0, 1.0, -1.0]
+    fv = np.array([[[x, y, z] for x, y in big] for z in zs], np.float32)
+    fv = np.concatenate([fv, np.array([[[-1, -1, 1], [0, 0, 1], [1, 1, 1]]], np.float32)])  # zero area
+    first, nf = np.array([0], np.int64), np.array([len(fv)], np.int64)
+    for K in (3, 8):
+        ref = orc.rasterize(fv, 1, 4, 4, 0.0, K)
+        out = native.rasterize_meshes(_dev(fv), _dev(first), _dev(nf), (4, 4), 0.0, K, False)
+        np.testing.assert_array_equal(out[0].cpu().numpy(), ref[0].astype(np.int32))
+        np.testing.assert_array_equal(out[1].cpu().numpy(), ref[1])
+    assert (ref[0][0, 1, 1] == [4, 1, 2, 0, 3, -1, -1, -1]).all()
+
+
+def test_rasterize_is_deterministic(native):
+    sc, fv, first, nf = _scene_faces(2, 3, seed=9)
+    a = native.rasterize_meshes(_dev(fv), _dev(first), _dev(nf), (64, 64), orc.blur_radius_for(1e-4), 25, True)
+    b = native.rasterize_meshes(_dev(fv), _dev(first), _dev(nf), (64, 64), orc.blur_radius_for(1e-4), 25, True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("N,level,H,W,sigma", [(2, 3, 64, 64, 1e-4), (2, 2, 24, 20, 3e-4), (1, 4, 128, 128, 1e-4),
+                                               (1, 3, 512, 512, 0.0)])
+def test_tile_lists_bit_exact(native, N, level, H, W, sigma):
+    sc, fv, first, nf = _scene_faces(N, level, seed=level)
+    blur = orc.blur_radius_for(sigma)
+    cap = 512
+    ref_counts, ref_lists = orc.tile_faces(fv, N, H, W, blur, 8, cap)
+    counts, lists = native.tile_faces(_dev(fv), _dev(first), _dev(nf), (H, W), blur, cap)
+    assert ref_counts.max() > 0 and ref_counts.max() <= cap
+    np.testing.assert_array_equal(counts.cpu().numpy(), ref_counts)
+    np.testing.assert_array_equal(lists.cpu().numpy(), ref_lists)
+
+
+@pytest.mark.parametrize("clip", [True, False])
+def test_rasterize_backward_matches_oracle(native, clip):
+    N, H, W, K = 2, 32, 32, 8
+    sc, fv, first, nf = _scene_faces(N, 2, seed=4)
+    blur = orc.blur_radius_for(1e-3)
+    p2f, zb, bar, ds = orc.rasterize(fv, N, H, W, blur, K, clip_bary=clip)
+    rs = np.random.RandomState(3)
+    gz, gb, gd = [rs.randn(*a.shape).astype(np.float32) for a in (zb, bar, ds)]
+    ref = orc.rasterize_backward(fv, p2f, gz, gb, gd, clip)
+    out = native.rasterize_meshes_backward(_dev(fv), _dev(p2f.astype(np.int32)), _dev(gz), _dev(gb), _dev(gd), clip)
+    assert rel_err(out.cpu().numpy(), ref) <= 1e-4
+    # only some upstream gradients given
+    ref_d = orc.rasterize_backward(fv, p2f, gz * 0, gb * 0, gd, clip)
+    out_d = native.rasterize_meshes_backward(_dev(fv), _dev(p2f.astype(np.int32)), None, None, _dev(gd), clip)
+    assert rel_err(out_d.cpu().numpy(), ref_d) <= 1e-4
+
+
+@pytest.mark.parametrize("mode,sigma,bg", [(orc.BLEND_CLIP_INSIDE, 1e-4, (1, 1, 1)), (orc.BLEND_SIGMOID, 1e-4, (.2, .5, .9)),
+                                           (orc.BLEND_HARD, 0.0, (1, 1, 1)), (orc.BLEND_CLIP_INSIDE, 1e-2, (0, 0, 0))])
+@pytest.mark.parametrize("shared", [False, True])
+def test_shade_blend_matches_oracle(native, mode, sigma, bg, shared):
+    N, H, W, K = 2, 32, 24, 9
+    sc, fv, first, nf = _scene_faces(N, 2, seed=6)
+    blur = orc.blur_radius_for(max(sigma, 1e-4))
+    p2f, zb, bar, ds = orc.rasterize(fv, N, H, W, blur, K)
+    faces = sc["faces"].numpy()
+    F = faces.shape[0]
+    fuv1 = sc["verts_uvs"].numpy()[faces]  # (F,3,2)
+    fuv = np.tile(fuv1[None], (N, 1, 1, 1)).reshape(-1, 3, 2)
+    maps = sc["maps"].numpy()[:, :16, :24].copy()  # non-square texture
+    ref = orc.layered_blend(orc.sample_textures(maps, fuv, p2f, bar), p2f, ds, sigma, bg, mode)
+    d = lambda a: _dev(a)
+    args = (d(p2f.astype(np.int32)), d(bar), d(ds), d(maps), d(fuv1 if shared else fuv), shared, d(first), sigma, bg,
+            None, mode)
+    img = native.shade_blend(*args)
+    np.testing.assert_allclose(img.cpu().numpy(), ref, atol=1e-5, rtol=0)
+    # backward
+    cot = np.random.RandomState(8).randn(*ref.shape).astype(np.float32)
+    tex = orc.sample_textures(maps, fuv, p2f, bar)
+    gcol, gds = orc.layered_blend_bwd(tex, p2f, ds, cot, sigma, bg, mode)
+    gmaps, gbar = orc.sample_textures_bwd(maps, fuv, p2f, bar, gcol)
+    gm, gb, gd = native.shade_blend_backward(d(cot), *args)
+    assert rel_err(gm.cpu().numpy(), gmaps) <= 1e-4
+    assert rel_err(gb.cpu().numpy(), gbar) <= 1e-4
+    if mode != orc.BLEND_HARD:
+        assert rel_err(gd.cpu().numpy(), gds) <= 1e-4
+    else:
+        assert (gd == 0).all()
+
+
+def test_shade_blend_ambient_colour(native):
+    N, H, W, K = 1, 16, 16, 4
+    sc, fv, first, nf = _scene_faces(N, 1, seed=2)
+    p2f, zb, bar, ds = orc.rasterize(fv, N, H, W, orc.blur_radius_for(1e-4), K)
+    fuv = sc["verts_uvs"].numpy()[sc["faces"].numpy()]
+    maps = sc["maps"].numpy()
+    amb = (0.7, 0.5, 0.9)
+    tex = orc.sample_textures(maps, fuv, p2f, bar) * np.array(amb, np.float32)  # renderer.py:163-164
+    ref = orc.layered_blend(tex, p2f, ds, 1e-4, (1, 1, 1), orc.BLEND_CLIP_INSIDE)
+    img = native.shade_blend(_dev(p2f.astype(np.int32)), _dev(bar), _dev(ds), _dev(maps), _dev(fuv), True, _dev(first),
+                             1e-4, (1, 1, 1), amb, orc.BLEND_CLIP_INSIDE)
+    np.testing.assert_allclose(img.cpu().numpy(), ref, atol=1e-5, rtol=0)
+
+
+def test_project_faces_matches_oracle(native):
+    N = 3
+    sc = synth.make_scene(N, level=2, seed=12)
+    verts, faces, R, T = sc["verts"].numpy(), sc["faces"].numpy(), sc["R"].numpy(), sc["T"].numpy()
+    vn = orc.project_verts(verts, R, T, S_FOV30)
+    ref = np.stack([vn[n][faces] for n in range(N)]).reshape(-1, 3, 3)
+    out = native.project_faces(_dev(verts), _dev(faces.astype(np.int32)), _dev(R), _dev(T), S_FOV30, S_FOV30)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)  # same op order, contraction off: identical bits
+    g = np.random.RandomState(1).randn(*ref.shape).astype(np.float32)
+    g_ndc = np.zeros_like(vn)
+    for n in range(N):
+        np.add.at(g_ndc[n], faces, g.reshape(N, -1, 3, 3)[n])
+    gv, gR, gT = orc.project_verts_bwd(verts, R, T, S_FOV30, g_ndc)
+    ov, oR, oT = native.project_faces_backward(_dev(verts), _dev(faces.astype(np.int32)), _dev(R), _dev(T), S_FOV30,
+                                               S_FOV30, _dev(g))
+    assert rel_err(ov.cpu().numpy(), gv) <= 1e-4
+    assert rel_err(oR.cpu().numpy(), gR) <= 1e-4
+    assert rel_err(oT.cpu().numpy(), gT) <= 1e-4
+
+
+def test_error_reporting(native):
+    fv = torch.zeros(1, 3, 3, device="cuda")
+    one = torch.zeros(1, dtype=torch.int64, device="cuda")
+    with pytest.raises(RuntimeError, match="perspective_correct"):
+        native.rasterize_meshes(fv, one, one + 1, (8, 8), 0.0, 1, False, perspective_correct=True)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        native.rasterize_meshes(fv, one, one + 1, (8, 8), 0.0, 100000, False)
+    with pytest.raises(ValueError, match="GPU"):
+        native.rasterize_meshes(fv.cpu(), one, one + 1, (8, 8), 0.0, 1, False)

@@ -1,0 +1,168 @@
+// Device-side geometry / shading primitives shared by the kernels of ur_render.hip.
+// gfx950 only.  Compiled with -ffp-contract=off: every fp32 operation below is meant to round exactly once, in the
+// order written, so that visibility decisions (pix_to_face, tile lists) are reproducible bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ur {
+
+constexpr float kEps = 1e-8f;
+constexpr int kTile = 8;  // a wavefront rasterizes one 8x8 pixel tile: lane = pixel
+
+// std::min / std::max semantics (NOT fminf/fmaxf: those differ on signed zeros)
+__device__ __forceinline__ float min_s(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float max_s(float a, float b) { return (a < b) ? b : a; }
+
+// NDC coordinate of the centre of pixel i of an axis with S1 pixels (S2 = the other axis).  +X left / +Y up: the
+// caller passes i = S1-1-column.
+__device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) {
+  float range = 2.0f;
+  if (S1 > S2) range = ((float)S1 / (float)S2) * range;
+  const float offset = range / 2.0f;
+  return -offset + (range * (float)i + offset) / (float)S1;
+}
+
+// Per-face record prepared once per call (k_face_prep): everything that does not depend on the pixel.
+//   rec[5*f+0] = v0x v0y v1x v1y
+//   rec[5*f+1] = v2x v2y z0  z1
+//   rec[5*f+2] = z2  denom l2(v0v1) l2(v0v2)          denom = edge(v2; v0, v1) + 1e-8
+//   rec[5*f+3] = l2(v1v2) d01x d01y d12x              dab = vb - va
+//   rec[5*f+4] = d12y d20x d20y 0
+//   bbox[f]    = xlo xhi ylo yhi                      blur-expanded; culled faces get xlo = +inf, xhi = -inf
+struct Face {
+  float v0x, v0y, v1x, v1y, v2x, v2y, z0, z1, z2, denom, l01, l02, l12, d01x, d01y, d12x, d12y, d20x, d20y;
+};
+
+__device__ __forceinline__ Face load_face(const float4* __restrict__ rec, int fid) {
+  const float4 a = rec[5 * (size_t)fid + 0], b = rec[5 * (size_t)fid + 1], c = rec[5 * (size_t)fid + 2],
+               d = rec[5 * (size_t)fid + 3], e = rec[5 * (size_t)fid + 4];
+  Face f;
+  f.v0x = a.x; f.v0y = a.y; f.v1x = a.z; f.v1y = a.w;
+  f.v2x = b.x; f.v2y = b.y; f.z0 = b.z; f.z1 = b.w;
+  f.z2 = c.x; f.denom = c.y; f.l01 = c.z; f.l02 = c.w;
+  f.l12 = d.x; f.d01x = d.y; f.d01y = d.z; f.d12x = d.w;
+  f.d12y = e.x; f.d20x = e.y; f.d20y = e.z;
+  return f;
+}
+
+// squared distance from p to segment a-b ; (bax, bay) = b - a and l2 = |b - a|^2 come from the record
+__device__ __forceinline__ float seg_dist(float px, float py, float ax, float ay, float bx, float by, float bax,
+                                          float bay, float l2) {
+  if (l2 <= kEps) {
+    const float dx = px - bx, dy = py - by;
+    return dx * dx + dy * dy;
+  }
+  const float pax = px - ax, pay = py - ay;
+  const float t = (bax * pax + bay * pay) / l2;
+  const float tt = min_s(max_s(t, 0.0f), 1.0f);
+  const float qx = ax + tt * bax, qy = ay + tt * bay;
+  const float dx = px - qx, dy = py - qy;
+  return dx * dx + dy * dy;
+}
+
+struct Eval {
+  float pz, sd, c0, c1, c2;  // depth, signed squared distance, output barycentrics
+  float w0, w1, w2;          // unclipped barycentrics
+  float d01, d02, d12;       // the three edge distances
+  bool inside;
+};
+
+// The (pixel, face) test.  Returns false when the face does not contribute to the pixel.  The bbox test against the
+// blur-expanded box must have been done by the caller (it needs the bbox, not the record).
+__device__ __forceinline__ bool eval_face(const Face& f, float px, float py, float blur, bool clip, Eval& o) {
+  const float e0 = (px - f.v1x) * f.d12y - (py - f.v1y) * f.d12x;  // edge(p; v1, v2)
+  const float e1 = (px - f.v2x) * f.d20y - (py - f.v2y) * f.d20x;  // edge(p; v2, v0)
+  const float e2 = (px - f.v0x) * f.d01y - (py - f.v0y) * f.d01x;  // edge(p; v0, v1)
+  o.w0 = e0 / f.denom; o.w1 = e1 / f.denom; o.w2 = e2 / f.denom;
+  float c0 = o.w0, c1 = o.w1, c2 = o.w2;
+  if (clip) {
+    c0 = max_s(c0, 0.0f); c1 = max_s(c1, 0.0f); c2 = max_s(c2, 0.0f);
+    const float s = max_s(c0 + c1 + c2, 1e-5f);
+    c0 = c0 / s; c1 = c1 / s; c2 = c2 / s;
+  }
+  float pz = c0 * f.z0 + c1 * f.z1 + c2 * f.z2;
+  if (pz < 0.0f) return false;
+  pz = pz + 0.0f;  // -0 -> +0: depth keys are compared as unsigned bit patterns
+  o.d01 = seg_dist(px, py, f.v0x, f.v0y, f.v1x, f.v1y, f.d01x, f.d01y, f.l01);
+  o.d02 = seg_dist(px, py, f.v0x, f.v0y, f.v2x, f.v2y, -f.d20x, -f.d20y, f.l02);
+  o.d12 = seg_dist(px, py, f.v1x, f.v1y, f.v2x, f.v2y, f.d12x, f.d12y, f.l12);
+  const float dist = min_s(min_s(o.d01, o.d02), o.d12);
+  o.inside = (o.w0 > 0.0f) && (o.w1 > 0.0f) && (o.w2 > 0.0f);
+  if (!o.inside && dist >= blur) return false;
+  o.pz = pz; o.sd = o.inside ? -dist : dist;
+  o.c0 = c0; o.c1 = c1; o.c2 = c2;
+  return true;
+}
+
+// ---- texture sampling: grid_sample(flip_y(map), 2uv-1, bilinear, align_corners=True, padding 'border') ----------
+struct Bilin {
+  int x0, y0;               // top-left texel in the FLIPPED map; x1 = x0+1, y1 = y0+1 may fall outside (weight 0)
+  float wnw, wne, wsw, wse;
+  float ix, iy;             // clipped source coordinates
+  float mx, my;             // d(ix)/d(gx), d(iy)/d(gy) including the border-clip mask
+};
+
+__device__ __forceinline__ Bilin bilin_setup(float u, float v, int Ht, int Wt) {
+  Bilin b;
+  const float gx = u * 2.0f - 1.0f, gy = v * 2.0f - 1.0f;
+  float ix = ((gx + 1.0f) / 2.0f) * (float)(Wt - 1);
+  float iy = ((gy + 1.0f) / 2.0f) * (float)(Ht - 1);
+  b.mx = (float)(Wt - 1) / 2.0f;
+  b.my = (float)(Ht - 1) / 2.0f;
+  if (ix <= 0.0f) { ix = 0.0f; b.mx = 0.0f; } else if (ix >= (float)(Wt - 1)) { ix = (float)(Wt - 1); b.mx = 0.0f; }
+  if (iy <= 0.0f) { iy = 0.0f; b.my = 0.0f; } else if (iy >= (float)(Ht - 1)) { iy = (float)(Ht - 1); b.my = 0.0f; }
+  b.ix = ix; b.iy = iy;
+  const float fx = floorf(ix), fy = floorf(iy);
+  b.x0 = (int)fx; b.y0 = (int)fy;
+  const float x1 = (float)(b.x0 + 1), y1 = (float)(b.y0 + 1);
+  b.wnw = (x1 - ix) * (y1 - iy);
+  b.wne = (ix - fx) * (y1 - iy);
+  b.wsw = (x1 - ix) * (iy - fy);
+  b.wse = (ix - fx) * (iy - fy);
+  return b;
+}
+
+// flat offsets (in floats) of the four texels inside one (Ht,Wt,3) map, or -1 when outside
+__device__ __forceinline__ void bilin_offsets(const Bilin& b, int Ht, int Wt, int& onw, int& one, int& osw, int& ose) {
+  const bool x1in = (b.x0 + 1) < Wt, y1in = (b.y0 + 1) < Ht;  // x0, y0 are always inside after the clip
+  const int r0 = (Ht - 1 - b.y0) * Wt, r1 = (Ht - 2 - b.y0) * Wt;  // flipped rows
+  onw = (r0 + b.x0) * 3;
+  one = x1in ? (r0 + b.x0 + 1) * 3 : -1;
+  osw = y1in ? (r1 + b.x0) * 3 : -1;
+  ose = (x1in && y1in) ? (r1 + b.x0 + 1) * 3 : -1;
+}
+
+__device__ __forceinline__ void sample_rgb(const float* __restrict__ map, const Bilin& b, int Ht, int Wt, float& r,
+                                           float& g, float& bl) {
+  int onw, one, osw, ose;
+  bilin_offsets(b, Ht, Wt, onw, one, osw, ose);
+  float acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a = 0.0f;
+    a += map[onw + c] * b.wnw;
+    a += (one >= 0 ? map[one + c] : 0.0f) * b.wne;
+    a += (osw >= 0 ? map[osw + c] : 0.0f) * b.wsw;
+    a += (ose >= 0 ? map[ose + c] : 0.0f) * b.wse;
+    acc[c] = a;
+  }
+  r = acc[0]; g = acc[1]; bl = acc[2];
+}
+
+// alpha of layered_rgb_blend (renderer.py:186-191); `valid` = pix_to_face >= 0
+__device__ __forceinline__ float layer_alpha(float d, bool valid, float sigma, int mode) {
+  if (!valid) return 0.0f;
+  if (mode == 0) return d <= 0.0f ? 1.0f : 0.0f;
+  if (mode == 1) return expf(-max_s(d, 0.0f) / sigma);
+  return 1.0f / (1.0f + expf(d / sigma));
+}
+
+// d(alpha)/d(dist) given alpha
+__device__ __forceinline__ float layer_dalpha(float d, float a, bool valid, float sigma, int mode) {
+  if (!valid || mode == 0) return 0.0f;
+  if (mode == 1) return (d >= 0.0f) ? a * (-1.0f / sigma) : 0.0f;
+  return a * (1.0f - a) * (-1.0f / sigma);
+}
+
+}  // namespace ur

@@ -1,0 +1,820 @@
+// ur_render.hip -- hand-written gfx950 (MI355X) kernels + the C ABI of include/unicorn_render.h.
+//
+// Execution model of the rasterizer (ur_rasterize_meshes / ur_tile_faces):
+//   * one WAVEFRONT owns one 8x8 pixel tile, lane = pixel (row-major inside the tile);
+//   * a workgroup of WPB waves (4, 2 or 1, chosen from K so that the per-lane top-K lists fit the 160 KB LDS) owns a
+//     coarse bin of 16x16 / 16x8 / 8x8 pixels;
+//   * coarse step: the workgroup scans the mesh's face bounding boxes (one face per thread, coalesced float4), a
+//     wave ballot + popcount prefix appends survivors to the bin list in LDS in ascending face order -- no atomics, so
+//     the lists are deterministic; the list is consumed in rounds, it cannot overflow;
+//   * fine step: each wave filters 64 bin entries at a time against its own tile (ballot again) and walks the set
+//     bits; the face record is read through a wave-uniform address, every lane tests its own pixel;
+//   * per-lane top-K: K (depth, face) keys packed as u64 = (bits(z) << 32 | face) in LDS, laid out [slot][lane] so
+//     that lane-consecutive 8-byte accesses are bank-conflict free; z >= 0, so unsigned order == (z, face) order;
+//   * output: keys are extracted in ascending order, barycentrics / distance are recomputed for the winners only.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/unicorn_render.h"
+#include "ur_device.h"
+
+using namespace ur;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return UR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// face records
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv, int64_t NF, float r, int cull,
+                                                   float4* __restrict__ bbox, float4* __restrict__ rec) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NF) return;
+  const float* p = fv + i * 9;
+  const float v0x = p[0], v0y = p[1], z0 = p[2], v1x = p[3], v1y = p[4], z1 = p[5], v2x = p[6], v2y = p[7], z2 = p[8];
+  const float zmax = max_s(max_s(z0, z1), z2);
+  const float face_area = (v0x - v1x) * (v2y - v1y) - (v0y - v1y) * (v2x - v1x);  // edge(v0; v1, v2)
+  const bool culled = (zmax < kEps) || (face_area <= kEps && face_area >= -kEps) || (cull && face_area < 0.0f);
+  float xlo = min_s(min_s(v0x, v1x), v2x) - r, xhi = max_s(max_s(v0x, v1x), v2x) + r;
+  float ylo = min_s(min_s(v0y, v1y), v2y) - r, yhi = max_s(max_s(v0y, v1y), v2y) + r;
+  if (culled) { xlo = __builtin_inff(); xhi = -__builtin_inff(); }
+  bbox[i] = make_float4(xlo, xhi, ylo, yhi);
+  const float denom = ((v2x - v0x) * (v1y - v0y) - (v2y - v0y) * (v1x - v0x)) + kEps;  // edge(v2; v0, v1) + eps
+  const float d01x = v1x - v0x, d01y = v1y - v0y, d12x = v2x - v1x, d12y = v2y - v1y, d20x = v0x - v2x,
+              d20y = v0y - v2y;
+  const float d02x = v2x - v0x, d02y = v2y - v0y;
+  rec[5 * i + 0] = make_float4(v0x, v0y, v1x, v1y);
+  rec[5 * i + 1] = make_float4(v2x, v2y, z0, z1);
+  rec[5 * i + 2] = make_float4(z2, denom, d01x * d01x + d01y * d01y, d02x * d02x + d02y * d02y);
+  rec[5 * i + 3] = make_float4(d12x * d12x + d12y * d12y, d01x, d01y, d12x);
+  rec[5 * i + 4] = make_float4(d12y, d20x, d20y, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// rasterizer
+// ------------------------------------------------------------------------------------------------------------------
+struct RasterParams {
+  const float4* bbox;
+  const float4* rec;
+  const int64_t* first;
+  const int64_t* nfaces;
+  int N, H, W, K;
+  float blur;
+  int clip;
+  int nbx, nby;  // bins per row / column
+  // outputs (fragments)
+  int32_t* p2f;
+  float* zbuf;
+  float* bary;
+  float* dists;
+  // tile-list export
+  int32_t* tl_counts;
+  int32_t* tl_lists;
+  int tl_cap;
+};
+
+constexpr int kBinCap = 1024;  // bin-list entries held in LDS per round
+
+template <int WPB> struct BinShape;
+template <> struct BinShape<4> { static constexpr int BW = 16, BH = 16; };
+template <> struct BinShape<2> { static constexpr int BW = 16, BH = 8; };
+template <> struct BinShape<1> { static constexpr int BW = 8, BH = 8; };
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float xc_hi, float yc_lo, float yc_hi) {
+  // bb = xlo xhi ylo yhi ; reject iff the whole centre interval is on one side of the box
+  return !(xc_hi < bb.x || xc_lo > bb.y || yc_hi < bb.z || yc_lo > bb.w);
+}
+
+// MODE 0: write fragments ; MODE 1: export tile lists
+template <int WPB, int MODE>
+__global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BW = BinShape<WPB>::BW, BH = BinShape<WPB>::BH;
+  constexpr int NT = WPB * 64;
+  // LDS carve: [bin list: kBinCap int32][wave counts: 2*WPB int32 (+pad to 16 B)][keys: WPB * K * 64 u64]
+  int32_t* s_bin = reinterpret_cast<int32_t*>(smem);
+  int32_t* s_wcnt = s_bin + kBinCap;
+  unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(smem + kBinCap * 4 + 64);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bins_per_img = P.nbx * P.nby;
+  const int n = blockIdx.x / bins_per_img;
+  const int b = blockIdx.x - n * bins_per_img;
+  const int by = b / P.nbx, bx = b - by * P.nbx;
+  const int H = P.H, W = P.W, K = P.K;
+
+  // bin extents in pixel-centre NDC (columns x0..x1, rows y0..y1, clamped to the image)
+  const int bx0 = bx * BW, by0 = by * BH;
+  const int bx1 = min(W, bx0 + BW) - 1, by1 = min(H, by0 + BH) - 1;
+  const float bxc_hi = pix_to_ndc(W - 1 - bx0, W, H), bxc_lo = pix_to_ndc(W - 1 - bx1, W, H);
+  const float byc_hi = pix_to_ndc(H - 1 - by0, H, W), byc_lo = pix_to_ndc(H - 1 - by1, H, W);
+
+  // this wave's tile
+  const int twx = (WPB == 4) ? (wave & 1) : (WPB == 2 ? wave : 0);
+  const int twy = (WPB == 4) ? (wave >> 1) : 0;
+  const int tx0 = bx0 + twx * kTile, ty0 = by0 + twy * kTile;
+  const bool tile_live = (tx0 < W) && (ty0 < H);
+  const int tx1 = min(W, tx0 + kTile) - 1, ty1 = min(H, ty0 + kTile) - 1;
+  const float txc_hi = pix_to_ndc(W - 1 - tx0, W, H), txc_lo = pix_to_ndc(W - 1 - max(tx1, tx0), W, H);
+  const float tyc_hi = pix_to_ndc(H - 1 - ty0, H, W), tyc_lo = pix_to_ndc(H - 1 - max(ty1, ty0), H, W);
+
+  // this lane's pixel
+  const int x = tx0 + (lane & 7), y = ty0 + (lane >> 3);
+  const bool pix_live = (x < W) && (y < H);
+  const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
+
+  unsigned long long* keys = s_keys_all + (size_t)wave * K * 64;
+  int cnt = 0;       // entries in this lane's list
+  int tl_count = 0;  // MODE 1: faces appended to this tile's list (wave-uniform)
+  const int64_t tile_id = ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * ((W + 7) / 8) + (tx0 >> 3);
+
+  const int64_t f0 = P.first[n];
+  const int nf = (int)P.nfaces[n];
+
+  int list_n = 0;
+  int it = 0;
+  for (int base = 0; base < nf; base += NT, ++it) {
+    // ---- coarse: append this chunk's survivors to the bin list, ascending --------------------------------------
+    if (base < nf) {
+      const int f = base + tid;
+      bool pass = false;
+      if (f < nf) pass = bbox_overlap(P.bbox[f0 + f], bxc_lo, bxc_hi, byc_lo, byc_hi);
+      const unsigned long long m = __ballot(pass);
+      if (lane == 0) s_wcnt[(it & 1) * WPB + wave] = __popcll(m);
+      __syncthreads();
+      int prefix = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) {
+        const int c = s_wcnt[(it & 1) * WPB + w];
+        prefix += (w < wave) ? c : 0;
+        total += c;
+      }
+      if (pass) s_bin[list_n + prefix + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)(f0 + f);
+      list_n += total;
+    }
+    const bool last = (base + NT >= nf);
+    if (!(last || list_n > kBinCap - NT)) continue;
+
+    // ---- fine: every wave consumes the bin list for its own tile -----------------------------------------------
+    __syncthreads();
+    if (tile_live) {
+      for (int c0 = 0; c0 < list_n; c0 += 64) {
+        const int j = c0 + lane;
+        int fid = -1;
+        bool pass = false;
+        float4 bb = make_float4(0, 0, 0, 0);
+        if (j < list_n) {
+          fid = s_bin[j];
+          bb = P.bbox[fid];
+          pass = bbox_overlap(bb, txc_lo, txc_hi, tyc_lo, tyc_hi);
+        }
+        unsigned long long m = __ballot(pass);
+        if (MODE == 1) {
+          if (pass) {
+            const int pos = tl_count + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < P.tl_cap) P.tl_lists[tile_id * P.tl_cap + pos] = fid;
+          }
+          tl_count += __popcll(m);
+          continue;
+        }
+        while (m) {
+          const int src = __builtin_ctzll(m);
+          m &= m - 1;
+          const int ufid = __builtin_amdgcn_readlane(fid, src);  // wave-uniform face id
+          const float4 ubb = make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.x), src)),
+                                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.y), src)),
+                                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.z), src)),
+                                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.w), src)));
+          const Face fc = load_face(P.rec, ufid);
+          bool hit = pix_live && !(px < ubb.x || px > ubb.y || py < ubb.z || py > ubb.w);
+          Eval ev;
+          if (hit) hit = eval_face(fc, px, py, P.blur, P.clip != 0, ev);
+          if (hit) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) | (unsigned)ufid;
+            if (cnt < K) {
+              keys[(size_t)cnt * 64 + lane] = key;
+              ++cnt;
+            } else {
+              // list full: replace the current maximum when the newcomer is smaller (rare path)
+              unsigned long long mx = 0;
+              int im = 0;
+              for (int i = 0; i < K; ++i) {
+                const unsigned long long kk = keys[(size_t)i * 64 + lane];
+                if (kk > mx) { mx = kk; im = i; }
+              }
+              if (key < mx) keys[(size_t)im * 64 + lane] = key;
+            }
+          }
+        }
+      }
+    }
+    list_n = 0;
+    __syncthreads();
+  }
+
+  if (MODE == 1) {
+    if (tile_live) {
+      if (lane == 0) P.tl_counts[tile_id] = tl_count;
+      for (int i = tl_count + lane; i < P.tl_cap; i += 64) P.tl_lists[tile_id * P.tl_cap + i] = -1;
+    }
+    return;
+  }
+  if (!tile_live) return;
+
+  // ---- output: ascending extraction, winners re-evaluated ----------------------------------------------------
+  const int64_t ebase = (((int64_t)n * H + y) * W + x) * K;
+  unsigned long long last_key = 0;
+  bool first_take = true;
+  const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(cnt));
+  for (int k = 0; k < maxcnt; ++k) {
+    if (k < cnt) {
+      unsigned long long best = ~0ull;
+      for (int i = 0; i < cnt; ++i) {
+        const unsigned long long kk = keys[(size_t)i * 64 + lane];
+        if ((first_take || kk > last_key) && kk < best) best = kk;
+      }
+      last_key = best;
+      first_take = false;
+      const int fid = (int)(unsigned)(best & 0xffffffffull);
+      const Face fc = load_face(P.rec, fid);
+      Eval ev;
+      eval_face(fc, px, py, P.blur, P.clip != 0, ev);
+      P.p2f[ebase + k] = fid;
+      if (P.zbuf) P.zbuf[ebase + k] = __uint_as_float((unsigned)(best >> 32));
+      if (P.dists) P.dists[ebase + k] = ev.sd;
+      if (P.bary) {
+        P.bary[(ebase + k) * 3 + 0] = ev.c0;
+        P.bary[(ebase + k) * 3 + 1] = ev.c1;
+        P.bary[(ebase + k) * 3 + 2] = ev.c2;
+      }
+    }
+  }
+  // padding: for every pixel of the tile the slots [cnt, K) are written by lanes that sweep k (contiguous stores)
+  for (int p = 0; p < 64; ++p) {
+    const int pcnt = __builtin_amdgcn_readlane(cnt, p);
+    const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
+    if (qx >= W || qy >= H) continue;
+    const int64_t qbase = (((int64_t)n * H + qy) * W + qx) * K;
+    for (int k = pcnt + lane; k < K; k += 64) {
+      P.p2f[qbase + k] = -1;
+      if (P.zbuf) P.zbuf[qbase + k] = -1.0f;
+      if (P.dists) P.dists[qbase + k] = -1.0f;
+    }
+    if (P.bary)
+      for (int k3 = pcnt * 3 + lane; k3 < K * 3; k3 += 64) P.bary[qbase * 3 + k3] = -1.0f;
+  }
+}
+
+size_t raster_lds_bytes(int wpb, int K) { return (size_t)kBinCap * 4 + 64 + (size_t)wpb * K * 64 * 8; }
+
+int pick_wpb(int K) {
+  const size_t budget = 160 * 1024;
+  if (raster_lds_bytes(4, K) <= budget) return 4;
+  if (raster_lds_bytes(2, K) <= budget) return 2;
+  if (raster_lds_bytes(1, K) <= budget) return 1;
+  return 0;
+}
+
+template <int WPB, int MODE> int launch_raster(RasterParams P, hipStream_t st) {
+  constexpr int BW = BinShape<WPB>::BW, BH = BinShape<WPB>::BH;
+  P.nbx = (P.W + BW - 1) / BW;
+  P.nby = (P.H + BH - 1) / BH;
+  const size_t lds = raster_lds_bytes(WPB, MODE == 1 ? 0 : P.K);
+  static thread_local size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_raster<WPB, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+    configured = lds;
+  }
+  const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
+  if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
+  hipLaunchKernelGGL((k_raster<WPB, MODE>), dim3((unsigned)blocks), dim3(WPB * 64), lds, st, P);
+  return check_launch("k_raster");
+}
+
+int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, void* ws, size_t ws_bytes, hipStream_t st,
+               float4** bbox, float4** rec) {
+  if (ws_bytes < ur_workspace_bytes(NF)) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes,
+                                                     ur_workspace_bytes(NF));
+  if (reinterpret_cast<uintptr_t>(ws) & 15) return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+  *bbox = reinterpret_cast<float4*>(ws);
+  *rec = *bbox + NF;
+  if (NF > 0) {
+    hipLaunchKernelGGL(k_face_prep, dim3((unsigned)((NF + 255) / 256)), dim3(256), 0, st, face_verts, NF,
+                       sqrtf(blur), cull, *bbox, *rec);
+    return check_launch("k_face_prep");
+  }
+  return UR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// rasterizer backward: one thread per (pixel, k) entry
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void edge_bwd(float px, float py, float ax, float ay, float bx, float by, float g,
+                                         float& gax, float& gay, float& gbx, float& gby) {
+  gax += g * (py - by);
+  gay += g * (bx - px);
+  gbx += -g * (py - ay);
+  gby += g * (px - ax);
+}
+
+__device__ __forceinline__ void seg_bwd(float px, float py, float ax, float ay, float bx, float by, float g, float& gax,
+                                        float& gay, float& gbx, float& gby) {
+  const float bax = bx - ax, bay = by - ay, pax = px - ax, pay = py - ay;
+  const float l2 = bax * bax + bay * bay;
+  if (l2 <= kEps) {
+    gbx += -(2.0f * (px - bx) * g);
+    gby += -(2.0f * (py - by) * g);
+    return;
+  }
+  const float t = (bax * pax + bay * pay) / l2;
+  const float tt = min_s(max_s(t, 0.0f), 1.0f);
+  const float qx = ax + tt * bax, qy = ay + tt * bay;
+  const float basex = g * 2.0f * (px - qx), basey = g * 2.0f * (py - qy);
+  gax += basex * (tt - 1.0f);
+  gay += basey * (tt - 1.0f);
+  gbx += -(basex * tt);
+  gby += -(basey * tt);
+}
+
+// gradient of one fragment wrt its face's nine coordinates, given upstream (gz, gb[3], gd)
+__device__ __forceinline__ void fragment_bwd(const float* __restrict__ fv, float px, float py, bool clip, float gz,
+                                             float gb0, float gb1, float gb2, float gdist, float out[9]) {
+  const float v0x = fv[0], v0y = fv[1], z0 = fv[2], v1x = fv[3], v1y = fv[4], z1 = fv[5], v2x = fv[6], v2y = fv[7],
+              z2 = fv[8];
+  const float denom = ((v2x - v0x) * (v1y - v0y) - (v2y - v0y) * (v1x - v0x)) + kEps;
+  const float e0 = (px - v1x) * (v2y - v1y) - (py - v1y) * (v2x - v1x);
+  const float e1 = (px - v2x) * (v0y - v2y) - (py - v2y) * (v0x - v2x);
+  const float e2 = (px - v0x) * (v1y - v0y) - (py - v0y) * (v1x - v0x);
+  const float w0 = e0 / denom, w1 = e1 / denom, w2 = e2 / denom;
+  float c0 = w0, c1 = w1, c2 = w2, s = 1.0f;
+  bool sum_clamped = false;
+  if (clip) {
+    c0 = max_s(w0, 0.0f); c1 = max_s(w1, 0.0f); c2 = max_s(w2, 0.0f);
+    const float sraw = c0 + c1 + c2;
+    sum_clamped = sraw < 1e-5f;
+    s = max_s(sraw, 1e-5f);
+  }
+  const float g0 = gb0 + gz * z0, g1 = gb1 + gz * z1, g2 = gb2 + gz * z2;
+  float gw0, gw1, gw2;
+  if (clip) {
+    const float gs = sum_clamped ? 0.0f : -(g0 * c0 + g1 * c1 + g2 * c2) / (s * s);
+    gw0 = (w0 > 0.0f) ? (g0 / s + gs) : 0.0f;
+    gw1 = (w1 > 0.0f) ? (g1 / s + gs) : 0.0f;
+    gw2 = (w2 > 0.0f) ? (g2 / s + gs) : 0.0f;
+  } else {
+    gw0 = g0; gw1 = g1; gw2 = g2;
+  }
+  const float ge0 = gw0 / denom, ge1 = gw1 / denom, ge2 = gw2 / denom;
+  const float gden = -(gw0 * w0 + gw1 * w1 + gw2 * w2) / denom;
+  float a0x = 0, a0y = 0, a1x = 0, a1y = 0, a2x = 0, a2y = 0;
+  edge_bwd(px, py, v1x, v1y, v2x, v2y, ge0, a1x, a1y, a2x, a2y);
+  edge_bwd(px, py, v2x, v2y, v0x, v0y, ge1, a2x, a2y, a0x, a0y);
+  edge_bwd(px, py, v0x, v0y, v1x, v1y, ge2, a0x, a0y, a1x, a1y);
+  // denom = edge(v2; v0, v1) + eps : v2 plays the role of the point
+  edge_bwd(v2x, v2y, v0x, v0y, v1x, v1y, gden, a0x, a0y, a1x, a1y);
+  a2x += gden * (v1y - v0y);
+  a2y += -gden * (v1x - v0x);
+  const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+  const float gd = inside ? -gdist : gdist;
+  const float d01 = seg_dist(px, py, v0x, v0y, v1x, v1y, v1x - v0x, v1y - v0y,
+                             (v1x - v0x) * (v1x - v0x) + (v1y - v0y) * (v1y - v0y));
+  const float d02 = seg_dist(px, py, v0x, v0y, v2x, v2y, v2x - v0x, v2y - v0y,
+                             (v2x - v0x) * (v2x - v0x) + (v2y - v0y) * (v2y - v0y));
+  const float d12 = seg_dist(px, py, v1x, v1y, v2x, v2y, v2x - v1x, v2y - v1y,
+                             (v2x - v1x) * (v2x - v1x) + (v2y - v1y) * (v2y - v1y));
+  if (d01 <= d02 && d01 <= d12) seg_bwd(px, py, v0x, v0y, v1x, v1y, gd, a0x, a0y, a1x, a1y);
+  else if (d02 <= d01 && d02 <= d12) seg_bwd(px, py, v0x, v0y, v2x, v2y, gd, a0x, a0y, a2x, a2y);
+  else seg_bwd(px, py, v1x, v1y, v2x, v2y, gd, a1x, a1y, a2x, a2y);
+  out[0] = a0x; out[1] = a0y; out[2] = gz * (c0 / s);
+  out[3] = a1x; out[4] = a1y; out[5] = gz * (c1 / s);
+  out[6] = a2x; out[7] = a2y; out[8] = gz * (c2 / s);
+}
+
+__global__ void __launch_bounds__(256) k_raster_bwd(const float* __restrict__ fv, const int32_t* __restrict__ p2f,
+                                                    const float* __restrict__ gz, const float* __restrict__ gb,
+                                                    const float* __restrict__ gd, int N, int H, int W, int K, int clip,
+                                                    float* __restrict__ gfv) {
+  const int64_t total = (int64_t)N * H * W * K;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int fid = p2f[e];
+    if (fid < 0) continue;
+    const int64_t pix = e / K;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
+    const float ugz = gz ? gz[e] : 0.0f, ugd = gd ? gd[e] : 0.0f;
+    const float ub0 = gb ? gb[e * 3 + 0] : 0.0f, ub1 = gb ? gb[e * 3 + 1] : 0.0f, ub2 = gb ? gb[e * 3 + 2] : 0.0f;
+    float g[9];
+    fragment_bwd(fv + (int64_t)fid * 9, px, py, clip != 0, ugz, ub0, ub1, ub2, ugd, g);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      if (g[i] != 0.0f) atomicAdd(gfv + (int64_t)fid * 9 + i, g[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// shading + layered blend (unfused from the rasterizer: consumes fragments).  One thread per pixel.
+// ------------------------------------------------------------------------------------------------------------------
+struct ShadeParams {
+  const int32_t* p2f;
+  const float* bary;
+  const float* dists;
+  const float* maps;
+  const float* fuv;
+  const int64_t* first;
+  int fuv_shared;
+  int N, H, W, K, Ht, Wt;
+  float sigma;
+  float bg[3];
+  float amb[3];
+  int use_amb;
+  int mode;
+  // forward
+  float* image;
+  // backward
+  const float* gimage;
+  float* gmaps;
+  float* gbary;
+  float* gdists;
+};
+
+__device__ __forceinline__ void frag_uv(const ShadeParams& P, int n, int fid, int64_t e, float& u, float& v,
+                                        const float*& fu) {
+  const int64_t fl = P.fuv_shared ? (int64_t)fid - P.first[n] : (int64_t)fid;
+  fu = P.fuv + fl * 6;
+  const float b0 = P.bary[e * 3 + 0], b1 = P.bary[e * 3 + 1], b2 = P.bary[e * 3 + 2];
+  u = (b0 * fu[0] + b1 * fu[2]) + b2 * fu[4];
+  v = (b0 * fu[1] + b1 * fu[3]) + b2 * fu[5];
+}
+
+__global__ void __launch_bounds__(256) k_shade_fwd(const ShadeParams P) {
+  const int64_t npix = (int64_t)P.N * P.H * P.W;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int64_t hw = (int64_t)P.H * P.W;
+  const int n = (int)(pix / hw);
+  const int64_t p = pix - (int64_t)n * hw;
+  const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+  float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = pix * P.K + k;
+    const int fid = P.p2f[e];
+    const bool valid = fid >= 0;
+    const float a = layer_alpha(P.dists[e], valid, P.sigma, P.mode);
+    float u = 0.0f, v = 0.0f;
+    const float* fu;
+    if (valid) frag_uv(P, n, fid, e, u, v, fu);
+    const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+    float cr, cg, cb;
+    sample_rgb(map, bl, P.Ht, P.Wt, cr, cg, cb);
+    if (P.use_amb) { cr *= P.amb[0]; cg *= P.amb[1]; cb *= P.amb[2]; }
+    r += occ * a * cr; g += occ * a * cg; b += occ * a * cb;
+    occ = occ * (1.0f - a);
+  }
+  float* img = P.image + (int64_t)n * 4 * hw + p;
+  img[0] = r + occ * 1.0f * P.bg[0];
+  img[hw] = g + occ * 1.0f * P.bg[1];
+  img[2 * hw] = b + occ * 1.0f * P.bg[2];
+  img[3 * hw] = 1.0f - occ;
+}
+
+// backward: occ_k kept in LDS ([k][thread], conflict free), then a back-to-front sweep
+__global__ void __launch_bounds__(64) k_shade_bwd(const ShadeParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_occ = reinterpret_cast<float*>(smem);  // K * 64 floats
+  const int64_t npix = (int64_t)P.N * P.H * P.W;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int t = threadIdx.x;
+  const int64_t hw = (int64_t)P.H * P.W;
+  const int n = (int)(pix / hw);
+  const int64_t p = pix - (int64_t)n * hw;
+  const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+  float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
+  const float* gi = P.gimage + (int64_t)n * 4 * hw + p;
+  const float g0 = gi[0], g1 = gi[hw], g2 = gi[2 * hw], g3 = gi[3 * hw];
+  float occ = 1.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = pix * P.K + k;
+    s_occ[k * 64 + t] = occ;
+    occ = occ * (1.0f - layer_alpha(P.dists[e], P.p2f[e] >= 0, P.sigma, P.mode));
+  }
+  float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+  float trans = 1.0f;
+  for (int k = P.K - 1; k >= 0; --k) {
+    const int64_t e = pix * P.K + k;
+    const int fid = P.p2f[e];
+    const bool valid = fid >= 0;
+    const float d = P.dists[e];
+    const float a = layer_alpha(d, valid, P.sigma, P.mode);
+    const float ok = s_occ[k * 64 + t];
+    float u = 0.0f, v = 0.0f;
+    const float* fu = nullptr;
+    if (valid) frag_uv(P, n, fid, e, u, v, fu);
+    const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+    int onw, one, osw, ose;
+    bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
+    float tex[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      tex[0][c] = map[onw + c];
+      tex[1][c] = one >= 0 ? map[one + c] : 0.0f;
+      tex[2][c] = osw >= 0 ? map[osw + c] : 0.0f;
+      tex[3][c] = ose >= 0 ? map[ose + c] : 0.0f;
+    }
+    float col[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.0f;
+      acc += tex[0][c] * bl.wnw; acc += tex[1][c] * bl.wne; acc += tex[2][c] * bl.wsw; acc += tex[3][c] * bl.wse;
+      col[c] = P.use_amb ? acc * P.amb[c] : acc;
+    }
+    const float cg = g0 * col[0] + g1 * col[1] + g2 * col[2];
+    const float ga = ok * (cg - behind) + g3 * ok * trans;
+    P.gdists[e] = ga * layer_dalpha(d, a, valid, P.sigma, P.mode);
+    // d loss / d texel colour (before ambient): occ_k * alpha_k * g * ambient
+    const float wgt = ok * a;
+    float gc[3] = {wgt * g0, wgt * g1, wgt * g2};
+    if (P.use_amb) { gc[0] *= P.amb[0]; gc[1] *= P.amb[1]; gc[2] *= P.amb[2]; }
+    float gix = 0.0f, giy = 0.0f;
+    if (wgt != 0.0f) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float g = gc[c];
+        if (gmap) {
+          atomicAdd(gmap + onw + c, g * bl.wnw);
+          if (one >= 0) atomicAdd(gmap + one + c, g * bl.wne);
+          if (osw >= 0) atomicAdd(gmap + osw + c, g * bl.wsw);
+          if (ose >= 0) atomicAdd(gmap + ose + c, g * bl.wse);
+        }
+        const float y1 = (float)(bl.y0 + 1), x1 = (float)(bl.x0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
+        gix -= tex[0][c] * (y1 - bl.iy) * g; giy -= tex[0][c] * (x1 - bl.ix) * g;
+        gix += tex[1][c] * (y1 - bl.iy) * g; giy -= tex[1][c] * (bl.ix - x0) * g;
+        gix -= tex[2][c] * (bl.iy - y0) * g; giy += tex[2][c] * (x1 - bl.ix) * g;
+        gix += tex[3][c] * (bl.iy - y0) * g; giy += tex[3][c] * (bl.ix - x0) * g;
+      }
+    }
+    float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
+    if (valid) {
+      const float gu = gix * bl.mx * 2.0f, gv = giy * bl.my * 2.0f;
+      gb0 = gu * fu[0] + gv * fu[1]; gb1 = gu * fu[2] + gv * fu[3]; gb2 = gu * fu[4] + gv * fu[5];
+    }
+    P.gbary[e * 3 + 0] = gb0; P.gbary[e * 3 + 1] = gb1; P.gbary[e * 3 + 2] = gb2;
+    behind = a * cg + (1.0f - a) * behind;
+    trans = trans * (1.0f - a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// camera projection fused with the face gather, and its backward
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_project_faces(const float* __restrict__ verts, const int32_t* __restrict__ faces,
+                                                       const float* __restrict__ R, const float* __restrict__ T,
+                                                       float sx, float sy, int N, int V, int F,
+                                                       float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, f, corner)
+  if (i >= (int64_t)N * F * 3) return;
+  const int n = (int)(i / ((int64_t)F * 3));
+  const int fc = (int)(i - (int64_t)n * F * 3);
+  const int vi = faces[fc];
+  const float* p = verts + ((int64_t)n * V + vi) * 3;
+  const float* r = R + (int64_t)n * 9;
+  const float* t = T + (int64_t)n * 3;
+  const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
+  const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
+  const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
+  out[i * 3 + 0] = (sx * vx) / vz;
+  out[i * 3 + 1] = (sy * vy) / vz;
+  out[i * 3 + 2] = vz;
+}
+
+__global__ void __launch_bounds__(256) k_project_faces_bwd(const float* __restrict__ verts,
+                                                           const int32_t* __restrict__ faces,
+                                                           const float* __restrict__ R, const float* __restrict__ T,
+                                                           float sx, float sy, int N, int V, int F,
+                                                           const float* __restrict__ gfv, float* __restrict__ gverts,
+                                                           float* __restrict__ gR, float* __restrict__ gT) {
+  // one block handles a slice of one mesh's face corners so that the R / T sums can be reduced in the block
+  const int n = blockIdx.y;
+  const int fc = blockIdx.x * blockDim.x + threadIdx.x;
+  float gv[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
+  if (fc < F * 3) {
+    const int vi = faces[fc];
+    const float* p = verts + ((int64_t)n * V + vi) * 3;
+    const float* r = R + (int64_t)n * 9;
+    const float* t = T + (int64_t)n * 3;
+    const float* g = gfv + ((int64_t)n * F * 3 + fc) * 3;
+    const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
+    const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
+    const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
+    gv[0] = g[0] * sx / vz;
+    gv[1] = g[1] * sy / vz;
+    gv[2] = g[2] - (g[0] * sx * vx + g[1] * sy * vy) / (vz * vz);
+    pr[0] = p[0]; pr[1] = p[1]; pr[2] = p[2];
+    if (gverts) {
+      float* go = gverts + ((int64_t)n * V + vi) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float a = gv[0] * r[i * 3 + 0] + gv[1] * r[i * 3 + 1] + gv[2] * r[i * 3 + 2];
+        if (a != 0.0f) atomicAdd(go + i, a);
+      }
+    }
+  }
+  if (!gR && !gT) return;
+  // 12 sums per mesh: wave shuffle reduction, then one atomic per wave
+  float s[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s[i * 3 + j] = pr[i] * gv[j];
+  s[9] = gv[0]; s[10] = gv[1]; s[11] = gv[2];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    float v = s[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    s[q] = v;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (gR)
+      for (int q = 0; q < 9; ++q) atomicAdd(gR + (int64_t)n * 9 + q, s[q]);
+    if (gT)
+      for (int q = 0; q < 3; ++q) atomicAdd(gT + (int64_t)n * 3 + q, s[9 + q]);
+  }
+}
+
+int fill_shade_params(ShadeParams& P, const int32_t* p2f, const float* bary, const float* dists, const float* maps,
+                      const float* fuv, int fuv_shared, const int64_t* first, int N, int H, int W, int K, int Ht, int Wt,
+                      float sigma, const float* bg, const float* amb, int mode) {
+  if (!p2f || !bary || !dists || !maps || !fuv || !bg) return fail(UR_ERR_INVALID_ARG, "null input pointer");
+  if (fuv_shared && !first) return fail(UR_ERR_INVALID_ARG, "face_uvs_shared needs mesh_first_face");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || Ht <= 0 || Wt <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (mode < 0 || mode > 2) return fail(UR_ERR_INVALID_ARG, "bad blend mode %d", mode);
+  if (mode != UR_BLEND_HARD && !(sigma > 0.0f)) return fail(UR_ERR_INVALID_ARG, "sigma must be > 0 for soft blending");
+  P.p2f = p2f; P.bary = bary; P.dists = dists; P.maps = maps; P.fuv = fuv; P.first = first; P.fuv_shared = fuv_shared;
+  P.N = N; P.H = H; P.W = W; P.K = K; P.Ht = Ht; P.Wt = Wt; P.sigma = sigma; P.mode = mode;
+  for (int i = 0; i < 3; ++i) { P.bg[i] = bg[i]; P.amb[i] = amb ? amb[i] : 1.0f; }
+  P.use_amb = amb && !(amb[0] == 1.0f && amb[1] == 1.0f && amb[2] == 1.0f);
+  P.image = nullptr; P.gimage = nullptr; P.gmaps = nullptr; P.gbary = nullptr; P.gdists = nullptr;
+  return UR_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================================
+// C ABI
+// ====================================================================================================================
+extern "C" {
+
+const char* ur_last_error(void) { return g_err; }
+int ur_abi_version(void) { return 1; }
+
+size_t ur_workspace_bytes(int64_t total_faces) {
+  // bbox (16 B) + record (80 B) per face, 16-byte granules
+  return (size_t)(total_faces < 1 ? 1 : total_faces) * 96;
+}
+
+int ur_project_faces(const float* verts, const int32_t* faces, const float* R, const float* T, float sx, float sy,
+                     int N, int V, int F, float* face_verts, void* stream) {
+  if (!verts || !faces || !R || !T || !face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  const int64_t total = (int64_t)N * F * 3;
+  if (total == 0) return UR_OK;
+  hipLaunchKernelGGL(k_project_faces, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts,
+                     faces, R, T, sx, sy, N, V, F, face_verts);
+  return check_launch("k_project_faces");
+}
+
+int ur_project_faces_backward(const float* verts, const int32_t* faces, const float* R, const float* T, float sx,
+                              float sy, int N, int V, int F, const float* grad_face_verts, float* grad_verts,
+                              float* grad_R, float* grad_T, void* stream) {
+  if (!verts || !faces || !R || !T || !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (N == 0 || F == 0 || (!grad_verts && !grad_R && !grad_T)) return UR_OK;
+  if (N > 65535) return fail(UR_ERR_INVALID_ARG, "N > 65535 meshes per call");
+  hipLaunchKernelGGL(k_project_faces_bwd, dim3((unsigned)((F * 3 + 255) / 256), (unsigned)N), dim3(256), 0,
+                     (hipStream_t)stream, verts, faces, R, T, sx, sy, N, V, F, grad_face_verts, grad_verts, grad_R,
+                     grad_T);
+  return check_launch("k_project_faces_bwd");
+}
+
+int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
+                        int64_t total_faces, int H, int W, float blur_radius, int K, int perspective_correct,
+                        int clip_barycentric_coords, int cull_backfaces, int32_t* pix_to_face, float* zbuf,
+                        float* bary, float* dists, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!face_verts || !mesh_first_face || !mesh_num_faces || !pix_to_face)
+    return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || total_faces < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (!(blur_radius >= 0.0f)) return fail(UR_ERR_INVALID_ARG, "blur_radius must be >= 0");
+  if (perspective_correct) return fail(UR_ERR_UNSUPPORTED, "perspective_correct=True is not supported");
+  if (total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "more than 2^31-1 faces");
+  const int wpb = pick_wpb(K);
+  if (!wpb) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d does not fit the 160 KB LDS (max %d)", K,
+                        (int)((160 * 1024 - kBinCap * 4 - 64) / 512));
+  if (N == 0) return UR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float4 *bbox, *rec;
+  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, workspace, workspace_bytes, st, &bbox, &rec);
+  if (rc) return rc;
+  RasterParams P{};
+  P.bbox = bbox; P.rec = rec; P.first = mesh_first_face; P.nfaces = mesh_num_faces;
+  P.N = N; P.H = H; P.W = W; P.K = K; P.blur = blur_radius; P.clip = clip_barycentric_coords;
+  P.p2f = pix_to_face; P.zbuf = zbuf; P.bary = bary; P.dists = dists;
+  if (wpb == 4) return launch_raster<4, 0>(P, st);
+  if (wpb == 2) return launch_raster<2, 0>(P, st);
+  return launch_raster<1, 0>(P, st);
+}
+
+int ur_tile_faces(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
+                  int64_t total_faces, int H, int W, float blur_radius, int cull_backfaces, int cap, int32_t* counts,
+                  int32_t* lists, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!face_verts || !mesh_first_face || !mesh_num_faces || !counts || !lists)
+    return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || cap <= 0 || total_faces < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (N == 0) return UR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float4 *bbox, *rec;
+  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, workspace, workspace_bytes, st, &bbox, &rec);
+  if (rc) return rc;
+  RasterParams P{};
+  P.bbox = bbox; P.rec = rec; P.first = mesh_first_face; P.nfaces = mesh_num_faces;
+  P.N = N; P.H = H; P.W = W; P.K = 1; P.blur = blur_radius; P.clip = 0;
+  P.tl_counts = counts; P.tl_lists = lists; P.tl_cap = cap;
+  return launch_raster<4, 1>(P, st);
+}
+
+int ur_rasterize_meshes_backward(const float* face_verts, const int32_t* pix_to_face, const float* grad_zbuf,
+                                 const float* grad_bary, const float* grad_dists, int N, int64_t total_faces, int H,
+                                 int W, int K, int perspective_correct, int clip_barycentric_coords,
+                                 float* grad_face_verts, void* stream) {
+  if (!face_verts || !pix_to_face || !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || total_faces < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (perspective_correct) return fail(UR_ERR_UNSUPPORTED, "perspective_correct=True is not supported");
+  const int64_t total = (int64_t)N * H * W * K;
+  if (total == 0 || (!grad_zbuf && !grad_bary && !grad_dists)) return UR_OK;
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(k_raster_bwd, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, N, H, W, K,
+                     clip_barycentric_coords, grad_face_verts);
+  return check_launch("k_raster_bwd");
+}
+
+int ur_shade_blend(const int32_t* pix_to_face, const float* bary, const float* dists, const float* maps,
+                   const float* face_uvs, int face_uvs_shared, const int64_t* mesh_first_face, int N, int H, int W,
+                   int K, int Ht, int Wt, float sigma, const float* background, const float* ambient, int mode,
+                   float* image, void* stream) {
+  ShadeParams P;
+  int rc = fill_shade_params(P, pix_to_face, bary, dists, maps, face_uvs, face_uvs_shared, mesh_first_face, N, H, W, K,
+                             Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (!image) return fail(UR_ERR_INVALID_ARG, "null image");
+  P.image = image;
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  hipLaunchKernelGGL(k_shade_fwd, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+  return check_launch("k_shade_fwd");
+}
+
+int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face, const float* bary,
+                            const float* dists, const float* maps, const float* face_uvs, int face_uvs_shared,
+                            const int64_t* mesh_first_face, int N, int H, int W, int K, int Ht, int Wt, float sigma,
+                            const float* background, const float* ambient, int mode, float* grad_maps,
+                            float* grad_bary, float* grad_dists, void* stream) {
+  ShadeParams P;
+  int rc = fill_shade_params(P, pix_to_face, bary, dists, maps, face_uvs, face_uvs_shared, mesh_first_face, N, H, W, K,
+                             Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (!grad_image || !grad_bary || !grad_dists) return fail(UR_ERR_INVALID_ARG, "null gradient pointer");
+  P.gimage = grad_image; P.gmaps = grad_maps; P.gbary = grad_bary; P.gdists = grad_dists;
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  const size_t lds = (size_t)K * 64 * 4;
+  if (lds > 64 * 1024) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d too large for the blend backward", K);
+  hipLaunchKernelGGL(k_shade_bwd, dim3((unsigned)((npix + 63) / 64)), dim3(64), lds, (hipStream_t)stream, P);
+  return check_launch("k_shade_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+"""ctypes binding of the C ABI in include/unicorn_render.h (built in-tree as unicorn_amd/lib/libunicorn_render.so).
+
+There is NO fallback: if the shared library is missing or a call fails, this module raises.  Tensors are handed over
+as raw device pointers; kernels are enqueued on torch's current HIP stream of the tensors' device.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libunicorn_render.so")
+
+BLEND_HARD, BLEND_CLIP_INSIDE, BLEND_SIGMOID = 0, 1, 2
+
+_lib = None
+
+_vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+_F3 = ctypes.c_float * 3
+
+_SIGNATURES = {
+    "ur_last_error": (ctypes.c_char_p, []),
+    "ur_abi_version": (_i, []),
+    "ur_workspace_bytes": (_sz, [_i64]),
+    "ur_project_faces": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp]),
+    "ur_project_faces_backward": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ur_rasterize_meshes": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
+                                 _vp]),
+    "ur_rasterize_meshes_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ur_tile_faces": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ur_shade_blend": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
+    "ur_shade_blend_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i,
+                                     _vp, _vp, _vp, _vp]),
+}
+
+
+def exported_symbols():
+    """Names include/unicorn_render.h declares (checked against the built library by the CPU tests)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                               f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().ur_last_error().decode()}")
+
+
+def _ptr(t, dtype=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("missing tensor")
+    if not t.is_cuda:
+        raise ValueError("unicorn_amd kernels need tensors on the GPU (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _on:
+    """`with _on(t):` = make t's GPU current, after checking that t lives on one."""
+
+    def __init__(self, t):
+        _ptr(t)
+        self._ctx = torch.cuda.device(t.device)
+
+    def __enter__(self):
+        return self._ctx.__enter__()
+
+    def __exit__(self, *a):
+        return self._ctx.__exit__(*a)
+
+
+def workspace_bytes(total_faces):
+    return int(lib().ur_workspace_bytes(int(total_faces)))
+
+
+def _workspace(total_faces, device):
+    return torch.empty(workspace_bytes(total_faces), dtype=torch.uint8, device=device)
+
+
+def project_faces(verts, faces, R, T, sx, sy):
+    """verts (N,V,3) f32, faces (F,3) i32, R (N,3,3), T (N,3) -> face_verts (N*F,3,3)"""
+    N, V = verts.shape[:2]
+    F = faces.shape[0]
+    out = torch.empty(N * F, 3, 3, dtype=torch.float32, device=verts.device)
+    with _on(verts):
+        _check(lib().ur_project_faces(_ptr(verts, torch.float32), _ptr(faces, torch.int32), _ptr(R, torch.float32),
+                                      _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(out), _stream(verts)),
+               "ur_project_faces")
+    return out
+
+
+def project_faces_backward(verts, faces, R, T, sx, sy, grad_face_verts, need_verts=True, need_R=True, need_T=True):
+    N, V = verts.shape[:2]
+    F = faces.shape[0]
+    gv = torch.zeros_like(verts) if need_verts else None
+    gR = torch.zeros_like(R) if need_R else None
+    gT = torch.zeros_like(T) if need_T else None
+    with _on(verts):
+        _check(lib().ur_project_faces_backward(_ptr(verts, torch.float32), _ptr(faces, torch.int32),
+                                               _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F,
+                                               _ptr(grad_face_verts, torch.float32), _ptr(gv, None, True),
+                                               _ptr(gR, None, True), _ptr(gT, None, True), _stream(verts)),
+               "ur_project_faces_backward")
+    return gv, gR, gT
+
+
+def rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_radius, faces_per_pixel,
+                     clip_barycentric_coords, cull_backfaces=False, perspective_correct=False, want_zbuf=True,
+                     want_bary=True, want_dists=True):
+    """face_verts (NF,3,3) -> pix_to_face i32 (N,H,W,K), zbuf, bary (N,H,W,K,3), dists"""
+    _ptr(face_verts, torch.float32)
+    H, W = image_size
+    N, K = int(mesh_first_face.shape[0]), int(faces_per_pixel)
+    NF = int(face_verts.shape[0])
+    dev = face_verts.device
+    p2f = torch.empty(N, H, W, K, dtype=torch.int32, device=dev)
+    zbuf = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if want_zbuf else None
+    bary = torch.empty(N, H, W, K, 3, dtype=torch.float32, device=dev) if want_bary else None
+    dists = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if want_dists else None
+    ws = _workspace(NF, dev)
+    with _on(face_verts):
+        _check(lib().ur_rasterize_meshes(_ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64),
+                                         _ptr(mesh_num_faces, torch.int64), N, NF, H, W, float(blur_radius), K,
+                                         int(perspective_correct), int(clip_barycentric_coords), int(cull_backfaces),
+                                         _ptr(p2f), _ptr(zbuf, None, True), _ptr(bary, None, True),
+                                         _ptr(dists, None, True), _ptr(ws), ws.numel(), _stream(face_verts)),
+               "ur_rasterize_meshes")
+    return p2f, zbuf, bary, dists
+
+
+def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, clip_barycentric_coords,
+                              perspective_correct=False):
+    N, H, W, K = pix_to_face.shape
+    gfv = torch.zeros_like(face_verts)
+    with _on(face_verts):
+        _check(lib().ur_rasterize_meshes_backward(_ptr(face_verts, torch.float32), _ptr(pix_to_face, torch.int32),
+                                                  _ptr(grad_zbuf, torch.float32, True),
+                                                  _ptr(grad_bary, torch.float32, True),
+                                                  _ptr(grad_dists, torch.float32, True), N, face_verts.shape[0], H, W,
+                                                  K, int(perspective_correct), int(clip_barycentric_coords),
+                                                  _ptr(gfv), _stream(face_verts)),
+               "ur_rasterize_meshes_backward")
+    return gfv
+
+
+def tile_faces(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_radius, cap, cull_backfaces=False):
+    H, W = image_size
+    N, NF = int(mesh_first_face.shape[0]), int(face_verts.shape[0])
+    dev = face_verts.device
+    TH, TW = (H + 7) // 8, (W + 7) // 8
+    counts = torch.empty(N, TH, TW, dtype=torch.int32, device=dev)
+    lists = torch.empty(N, TH, TW, cap, dtype=torch.int32, device=dev)
+    ws = _workspace(NF, dev)
+    with _on(face_verts):
+        _check(lib().ur_tile_faces(_ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64),
+                                   _ptr(mesh_num_faces, torch.int64), N, NF, H, W, float(blur_radius),
+                                   int(cull_backfaces), int(cap), _ptr(counts), _ptr(lists), _ptr(ws), ws.numel(),
+                                   _stream(face_verts)), "ur_tile_faces")
+    return counts, lists
+
+
+def _rgb(v):
+    return None if v is None else _F3(*[float(x) for x in v])
+
+
+def shade_blend(pix_to_face, bary, dists, maps, face_uvs, face_uvs_shared, mesh_first_face, sigma, background,
+                ambient, mode):
+    N, H, W, K = pix_to_face.shape
+    Ht, Wt = maps.shape[1:3]
+    image = torch.empty(N, 4, H, W, dtype=torch.float32, device=maps.device)
+    with _on(maps):
+        _check(lib().ur_shade_blend(_ptr(pix_to_face, torch.int32), _ptr(bary, torch.float32),
+                                    _ptr(dists, torch.float32), _ptr(maps, torch.float32),
+                                    _ptr(face_uvs, torch.float32), int(face_uvs_shared),
+                                    _ptr(mesh_first_face, torch.int64, True), N, H, W, K, Ht, Wt, float(sigma),
+                                    ctypes.cast(_rgb(background), _vp), ctypes.cast(_rgb(ambient), _vp)
+                                    if ambient is not None else None, int(mode), _ptr(image), _stream(maps)),
+               "ur_shade_blend")
+    return image
+
+
+def shade_blend_backward(grad_image, pix_to_face, bary, dists, maps, face_uvs, face_uvs_shared, mesh_first_face,
+                         sigma, background, ambient, mode, need_maps=True):
+    N, H, W, K = pix_to_face.shape
+    Ht, Wt = maps.shape[1:3]
+    gmaps = torch.zeros_like(maps) if need_maps else None
+    gbary = torch.empty_like(bary)
+    gdists = torch.empty_like(dists)
+    with _on(maps):
+        _check(lib().ur_shade_blend_backward(_ptr(grad_image, torch.float32), _ptr(pix_to_face, torch.int32),
+                                             _ptr(bary, torch.float32), _ptr(dists, torch.float32),
+                                             _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32),
+                                             int(face_uvs_shared), _ptr(mesh_first_face, torch.int64, True), N, H, W,
+                                             K, Ht, Wt, float(sigma), ctypes.cast(_rgb(background), _vp),
+                                             ctypes.cast(_rgb(ambient), _vp) if ambient is not None else None,
+                                             int(mode), _ptr(gmaps, None, True), _ptr(gbary), _ptr(gdists),
+                                             _stream(maps)), "ur_shade_blend_backward")
+    return gmaps, gbary, gdists
