@@ -48,16 +48,18 @@ size_t ur_workspace_bytes(int64_t total_faces);
  * Replaces: MeshRasterizer.transform + cameras.transform_points + verts_packed[faces_packed]
  *           (pytorch3d, reached from renderer.py:48 with the cameras of renderer.py:59-63).
  *   view = v @ R[n] + T[n] ; x_ndc = sx * x / z ; y_ndc = sy * y / z ; z_ndc = z_view
- *   verts (N,V,3), faces (F,3) int32 shared topology, R (N,3,3), T (N,3) -> face_verts (N*F,3,3)
+ *   verts (N,V,3) ; faces int64, mesh n reads faces + n*faces_mesh_stride (elements): stride 0 = one (F,3) topology
+ *   shared by the batch (unicorn.py:283 expands it), stride F*3 = per-mesh (N,F,3) ; R (N,3,3), T (N,3)
+ *   -> face_verts (N*F,3,3)
  */
-int ur_project_faces(const float* verts, const int32_t* faces, const float* R, const float* T, float sx, float sy,
-                     int N, int V, int F, float* face_verts, void* stream);
+int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                     const float* T, float sx, float sy, int N, int V, int F, float* face_verts, void* stream);
 
 /* Backward of ur_project_faces: grad_face_verts (N*F,3,3) -> grad_verts (N,V,3), grad_R (N,3,3), grad_T (N,3).
  * All three outputs must be zero-filled by the caller (they are accumulated with float atomics); any may be NULL. */
-int ur_project_faces_backward(const float* verts, const int32_t* faces, const float* R, const float* T, float sx,
-                              float sy, int N, int V, int F, const float* grad_face_verts, float* grad_verts,
-                              float* grad_R, float* grad_T, void* stream);
+int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                              const float* T, float sx, float sy, int N, int V, int F, const float* grad_face_verts,
+                              float* grad_verts, float* grad_R, float* grad_T, void* stream);
 
 /*
  * Per-pixel top-K rasterization.

@@ -191,14 +191,14 @@ def test_project_faces_matches_oracle(native):
     verts, faces, R, T = sc["verts"].numpy(), sc["faces"].numpy(), sc["R"].numpy(), sc["T"].numpy()
     vn = orc.project_verts(verts, R, T, S_FOV30)
     ref = np.stack([vn[n][faces] for n in range(N)]).reshape(-1, 3, 3)
-    out = native.project_faces(_dev(verts), _dev(faces.astype(np.int32)), _dev(R), _dev(T), S_FOV30, S_FOV30)
+    out = native.project_faces(_dev(verts), _dev(faces), _dev(R), _dev(T), S_FOV30, S_FOV30)
     np.testing.assert_array_equal(out.cpu().numpy(), ref)  # same op order, contraction off: identical bits
     g = np.random.RandomState(1).randn(*ref.shape).astype(np.float32)
     g_ndc = np.zeros_like(vn)
     for n in range(N):
         np.add.at(g_ndc[n], faces, g.reshape(N, -1, 3, 3)[n])
     gv, gR, gT = orc.project_verts_bwd(verts, R, T, S_FOV30, g_ndc)
-    ov, oR, oT = native.project_faces_backward(_dev(verts), _dev(faces.astype(np.int32)), _dev(R), _dev(T), S_FOV30,
+    ov, oR, oT = native.project_faces_backward(_dev(verts), _dev(faces), _dev(R), _dev(T), S_FOV30,
                                                S_FOV30, _dev(g))
     assert rel_err(ov.cpu().numpy(), gv) <= 1e-4
     assert rel_err(oR.cpu().numpy(), gR) <= 1e-4

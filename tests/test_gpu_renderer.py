@@ -1,0 +1,177 @@
+"""End-to-end GPU parity of the `Renderer` drop-in (reference API: src/model/renderer.py:25-116) against the CPU
+oracle's whole-path restatement, at the BASELINE.json configurations (batch reduced where the oracle would be slow)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import orc
+from unicorn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(N, level, img, K, seed=0, sigma=1e-4, tex=64, cam=None, expand=True, **rkw):
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesUV
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(N, level=level, tex_size=tex, seed=seed)
+    cam = cam or {"name": "fov", "fov": 30}
+    rend = Renderer(img, cameras=cam, faces_per_pixel=K, sigma=sigma, **rkw).to(dev)
+    verts = sc["verts"].to(dev).requires_grad_(True)
+    maps = sc["maps"].to(dev).requires_grad_(True)
+    R = sc["R"].to(dev).requires_grad_(True)
+    T = sc["T"].to(dev).requires_grad_(True)
+    faces, uvs = sc["faces"].to(dev), sc["verts_uvs"].to(dev)
+    if expand:  # unicorn.py:283
+        fb, ub = faces[None].expand(N, -1, -1), uvs[None].expand(N, -1, -1)
+    else:
+        fb, ub = faces[None].repeat(N, 1, 1), uvs[None].repeat(N, 1, 1)
+    meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
+    return sc, rend, meshes, (verts, maps, R, T)
+
+
+def _oracle(sc, H, W, K, s, sigma, cot=None, **kw):
+    N = sc["verts"].shape[0]
+    return orc.render_fwd_bwd(sc["verts"].numpy(), sc["faces"].numpy(), sc["R"].numpy(), sc["T"].numpy(),
+                              sc["maps"].numpy(), sc["verts_uvs"][None].expand(N, -1, -1).numpy(), H, W, K, s,
+                              sigma=sigma, grad_image=cot, **kw)
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-20))
+
+
+S30 = float(1.0 / np.tan(np.deg2rad(15.0)))
+
+CASES = [
+    # N, level, img, K, camera
+    (4, 3, 64, 50, None),                                                          # configs[1]: sn, K=50
+    (4, 3, 64, 25, None),                                                          # configs[2]: car.yml, K=25
+    (2, 3, 128, 50, None),                                                         # headline: 128^2, K=50
+    (1, 4, 128, 50, {"name": "perspective", "focal_length": 3.732050895690918}),   # configs[3]: finer mesh, sn camera
+    (2, 2, (40, 56), 10, None),                                                    # non-square, ragged tiles
+]
+
+
+@pytest.mark.parametrize("N,level,img,K,cam", CASES)
+def test_forward_backward_match_oracle(N, level, img, K, cam):
+    sc, rend, meshes, (verts, maps, R, T) = _setup(N, level, img, K, seed=K + level, cam=cam)
+    H, W = (img, img) if isinstance(img, int) else img
+    out = rend(meshes, R, T)
+    assert out.shape == (N, 4, H, W) and out.dtype == torch.float32
+    cot = np.random.RandomState(0).randn(N, 4, H, W).astype(np.float32)
+    (out * torch.from_numpy(cot).cuda()).sum().backward()
+    s = S30 if cam is None else cam["focal_length"]
+    ref, (gv, gR, gT, gm) = _oracle(sc, H, W, K, s, 1e-4, cot)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=0)
+    assert 0.05 < ref[:, 3].mean() < 0.9
+    assert rel_err(maps.grad.cpu().numpy(), gm) <= 1e-4
+    assert rel_err(verts.grad.cpu().numpy(), gv) <= 1e-4
+    assert rel_err(T.grad.cpu().numpy(), gT) <= 1e-4
+    assert rel_err(R.grad.cpu().numpy(), gR) <= 1e-4
+
+
+def test_sigmoid_blend_and_background():
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, 32, 12, seed=3, sigma=1e-3, clip_inside=False,
+                                                   background_color=(0.1, 0.6, 0.3))
+    out = rend(meshes, R, T)
+    cot = np.random.RandomState(1).randn(*out.shape).astype(np.float32)
+    (out * torch.from_numpy(cot).cuda()).sum().backward()
+    ref, (gv, gR, gT, gm) = _oracle(sc, 32, 32, 12, S30, 1e-3, cot, clip_inside=False, background=(0.1, 0.6, 0.3))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=0)
+    assert rel_err(verts.grad.cpu().numpy(), gv) <= 1e-4 and rel_err(maps.grad.cpu().numpy(), gm) <= 1e-4
+
+
+def test_only_requested_gradients_are_produced():
+    # pose step: meshes detached, grads to R, T only (unicorn.py:227-228); 3D step: R, T detached (:230)
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, 32, 10, seed=5)
+    out = rend(meshes.detach(), R, T)
+    out.sum().backward()
+    assert verts.grad is None and maps.grad is None and R.grad is not None and T.grad is not None
+    gR = R.grad.clone()
+    R.grad = T.grad = None
+    out = rend(meshes, R.detach(), T.detach())
+    out.sum().backward()
+    assert verts.grad is not None and maps.grad is not None and R.grad is None
+    # same numbers as when everything is differentiated at once
+    sc2, rend2, meshes2, (v2, m2, R2, T2) = _setup(2, 2, 32, 10, seed=5)
+    rend2(meshes2, R2, T2).sum().backward()
+    assert rel_err(gR.cpu().numpy(), R2.grad.cpu().numpy()) <= 1e-5
+    assert rel_err(verts.grad.cpu().numpy(), v2.grad.cpu().numpy()) <= 1e-5
+
+
+def test_repeat_tiles_candidates_k_major():
+    """utils/mesh.py:43-71 + unicorn.py:232-233: K pose candidates per mesh, K-major."""
+    from unicorn_amd.structures import repeat
+    B, KP = 2, 3
+    sc, rend, meshes, (verts, maps, R, T) = _setup(B, 2, 32, 10, seed=7)
+    sc6 = synth.make_scene(B * KP, level=2, seed=11)
+    R6, T6 = sc6["R"].cuda(), sc6["T"].cuda()
+    out = rend(repeat(meshes, KP), R6, T6)
+    for k in range(KP):
+        one = rend(meshes, R6[k * B:(k + 1) * B], T6[k * B:(k + 1) * B])
+        assert torch.equal(out[k * B:(k + 1) * B], one)
+    out.sum().backward()
+    assert verts.grad.shape == (B, verts.shape[1], 3) and maps.grad.abs().sum() > 0
+
+
+def test_list_constructed_meshes_equal_padded():
+    """the reference's repeat() builds Meshes from python lists of cloned tensors"""
+    from unicorn_amd.structures import Meshes, TexturesUV
+    sc, rend, meshes, (verts, maps, R, T) = _setup(3, 2, 32, 10, seed=9)
+    faces = sc["faces"].cuda()
+    m2 = Meshes([v.clone() for v in verts.detach()], [faces.clone() for _ in range(3)],
+                TexturesUV(maps.detach(), faces[None].repeat(3, 1, 1), sc["verts_uvs"].cuda()[None].repeat(3, 1, 1)))
+    assert torch.equal(rend(meshes, R, T), rend(m2, R, T))
+
+
+def test_viz_path_matches_oracle():
+    """renderer.py:51-57,119-124: hard raster at 2x viz_size, K=1, sigma=0 blend, 2x2 average pool; no grad."""
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 3, 64, 25, seed=4, viz_size=(48, 48))
+    out = rend(meshes, R, T, viz_purpose=True)
+    assert out.shape == (2, 4, 48, 48) and not out.requires_grad
+    ref = _oracle(sc, 96, 96, 1, S30, 0.0, blur_radius=0.0)
+    ref = ref.reshape(2, 4, 48, 2, 48, 2).mean((3, 5))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-5, rtol=0)
+
+
+def test_compute_vertex_visibility():
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, 32, 5, seed=6, viz_size=(32, 32))
+    vis = rend.compute_vertex_visibility(meshes, R, T)
+    N, V = verts.shape[:2]
+    assert vis.shape == (N, V) and vis.dtype == torch.bool
+    vn = orc.project_verts(sc["verts"].numpy(), sc["R"].numpy(), sc["T"].numpy(), S30)
+    faces = sc["faces"].numpy()
+    fv = np.stack([vn[n][faces] for n in range(N)]).reshape(-1, 3, 3)
+    p2f = orc.rasterize(fv, N, 64, 64, 0.0, 1)[0]
+    expect = np.zeros((N, V), bool)
+    F = faces.shape[0]
+    for f in np.unique(p2f[p2f >= 0]):
+        expect[f // F, faces[f % F]] = True
+    np.testing.assert_array_equal(vis.cpu().numpy(), expect)
+    assert 0.2 < expect.mean() < 0.8  # roughly the camera-facing half
+
+
+def test_fragments_surface():
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, 32, 5, seed=6)
+    frag = rend.renderer.rasterizer(meshes, R=R, T=T)
+    assert frag.pix_to_face.dtype == torch.int64 and frag.pix_to_face.shape == (2, 32, 32, 5)
+    assert frag.bary_coords.shape == (2, 32, 32, 5, 3) and frag.zbuf.shape == frag.dists.shape == (2, 32, 32, 5)
+    tex = meshes.sample_textures(frag)  # (N,H,W,K,3) texels, as pytorch3d returns them
+    vn = orc.project_verts(sc["verts"].numpy(), sc["R"].numpy(), sc["T"].numpy(), S30)
+    faces = sc["faces"].numpy()
+    fv = np.stack([vn[n][faces] for n in range(2)]).reshape(-1, 3, 3)
+    p2f, zb, bar, ds = orc.rasterize(fv, 2, 32, 32, orc.blur_radius_for(1e-4), 5)
+    fuv = np.tile(sc["verts_uvs"].numpy()[faces][None], (2, 1, 1, 1)).reshape(-1, 3, 2)
+    np.testing.assert_allclose(tex.detach().cpu().numpy(), orc.sample_textures(sc["maps"].numpy(), fuv, p2f, bar),
+                               atol=1e-5)
+
+
+def test_init_kwargs_roundtrip_and_unsupported():
+    from unicorn_amd.renderer import Renderer
+    kw = {"cameras": {"name": "perspective", "focal_length": 3.73}, "faces_per_pixel": 50, "sigma": 1e-4}
+    r = Renderer(64, **kw)
+    assert r.init_kwargs == kw and r.init_kwargs is not r.init_kwargs
+    assert Renderer(64, **r.init_kwargs).renderer.rasterizer.raster_settings.faces_per_pixel == 50
+    with pytest.raises(NotImplementedError):
+        Renderer(64, layered_shader=False)

@@ -591,15 +591,16 @@ __global__ void __launch_bounds__(64) k_shade_bwd(const ShadeParams P) {
 // ------------------------------------------------------------------------------------------------------------------
 // camera projection fused with the face gather, and its backward
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_project_faces(const float* __restrict__ verts, const int32_t* __restrict__ faces,
-                                                       const float* __restrict__ R, const float* __restrict__ T,
+__global__ void __launch_bounds__(256) k_project_faces(const float* __restrict__ verts, const int64_t* __restrict__ faces,
+                                                       int64_t fstride, const float* __restrict__ R,
+                                                       const float* __restrict__ T,
                                                        float sx, float sy, int N, int V, int F,
                                                        float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, f, corner)
   if (i >= (int64_t)N * F * 3) return;
   const int n = (int)(i / ((int64_t)F * 3));
   const int fc = (int)(i - (int64_t)n * F * 3);
-  const int vi = faces[fc];
+  const int64_t vi = faces[(int64_t)n * fstride + fc];
   const float* p = verts + ((int64_t)n * V + vi) * 3;
   const float* r = R + (int64_t)n * 9;
   const float* t = T + (int64_t)n * 3;
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(256) k_project_faces(const float* __restrict__
 }
 
 __global__ void __launch_bounds__(256) k_project_faces_bwd(const float* __restrict__ verts,
-                                                           const int32_t* __restrict__ faces,
+                                                           const int64_t* __restrict__ faces, int64_t fstride,
                                                            const float* __restrict__ R, const float* __restrict__ T,
                                                            float sx, float sy, int N, int V, int F,
                                                            const float* __restrict__ gfv, float* __restrict__ gverts,
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(256) k_project_faces_bwd(const float* __restri
   const int fc = blockIdx.x * blockDim.x + threadIdx.x;
   float gv[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
   if (fc < F * 3) {
-    const int vi = faces[fc];
+    const int64_t vi = faces[(int64_t)n * fstride + fc];
     const float* p = verts + ((int64_t)n * V + vi) * 3;
     const float* r = R + (int64_t)n * 9;
     const float* t = T + (int64_t)n * 3;
@@ -697,27 +698,27 @@ size_t ur_workspace_bytes(int64_t total_faces) {
   return (size_t)(total_faces < 1 ? 1 : total_faces) * 96;
 }
 
-int ur_project_faces(const float* verts, const int32_t* faces, const float* R, const float* T, float sx, float sy,
-                     int N, int V, int F, float* face_verts, void* stream) {
+int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                     const float* T, float sx, float sy, int N, int V, int F, float* face_verts, void* stream) {
   if (!verts || !faces || !R || !T || !face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
   const int64_t total = (int64_t)N * F * 3;
   if (total == 0) return UR_OK;
   hipLaunchKernelGGL(k_project_faces, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts,
-                     faces, R, T, sx, sy, N, V, F, face_verts);
+                     faces, faces_mesh_stride, R, T, sx, sy, N, V, F, face_verts);
   return check_launch("k_project_faces");
 }
 
-int ur_project_faces_backward(const float* verts, const int32_t* faces, const float* R, const float* T, float sx,
-                              float sy, int N, int V, int F, const float* grad_face_verts, float* grad_verts,
-                              float* grad_R, float* grad_T, void* stream) {
+int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                              const float* T, float sx, float sy, int N, int V, int F, const float* grad_face_verts,
+                              float* grad_verts, float* grad_R, float* grad_T, void* stream) {
   if (!verts || !faces || !R || !T || !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
   if (N == 0 || F == 0 || (!grad_verts && !grad_R && !grad_T)) return UR_OK;
   if (N > 65535) return fail(UR_ERR_INVALID_ARG, "N > 65535 meshes per call");
   hipLaunchKernelGGL(k_project_faces_bwd, dim3((unsigned)((F * 3 + 255) / 256), (unsigned)N), dim3(256), 0,
-                     (hipStream_t)stream, verts, faces, R, T, sx, sy, N, V, F, grad_face_verts, grad_verts, grad_R,
-                     grad_T);
+                     (hipStream_t)stream, verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts,
+                     grad_verts, grad_R, grad_T);
   return check_launch("k_project_faces_bwd");
 }
 

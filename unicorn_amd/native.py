@@ -22,8 +22,8 @@ _SIGNATURES = {
     "ur_last_error": (ctypes.c_char_p, []),
     "ur_abi_version": (_i, []),
     "ur_workspace_bytes": (_sz, [_i64]),
-    "ur_project_faces": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp]),
-    "ur_project_faces_backward": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ur_project_faces": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp]),
+    "ur_project_faces_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ur_rasterize_meshes": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                  _vp]),
     "ur_rasterize_meshes_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -98,26 +98,34 @@ def _workspace(total_faces, device):
     return torch.empty(workspace_bytes(total_faces), dtype=torch.uint8, device=device)
 
 
+def _faces_layout(faces, N):
+    if faces.dim() == 2:
+        return int(faces.shape[0]), 0
+    if faces.dim() == 3 and faces.shape[0] == N:
+        return int(faces.shape[1]), int(faces.shape[1]) * 3
+    raise ValueError("faces must be (F,3) or (N,F,3)")
+
+
 def project_faces(verts, faces, R, T, sx, sy):
-    """verts (N,V,3) f32, faces (F,3) i32, R (N,3,3), T (N,3) -> face_verts (N*F,3,3)"""
+    """verts (N,V,3) f32, faces i64 (F,3) shared or (N,F,3) per mesh, R (N,3,3), T (N,3) -> face_verts (N*F,3,3)"""
     N, V = verts.shape[:2]
-    F = faces.shape[0]
+    F, fstride = _faces_layout(faces, N)
     out = torch.empty(N * F, 3, 3, dtype=torch.float32, device=verts.device)
     with _on(verts):
-        _check(lib().ur_project_faces(_ptr(verts, torch.float32), _ptr(faces, torch.int32), _ptr(R, torch.float32),
-                                      _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(out), _stream(verts)),
-               "ur_project_faces")
+        _check(lib().ur_project_faces(_ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
+                                      _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(out),
+                                      _stream(verts)), "ur_project_faces")
     return out
 
 
 def project_faces_backward(verts, faces, R, T, sx, sy, grad_face_verts, need_verts=True, need_R=True, need_T=True):
     N, V = verts.shape[:2]
-    F = faces.shape[0]
+    F, fstride = _faces_layout(faces, N)
     gv = torch.zeros_like(verts) if need_verts else None
     gR = torch.zeros_like(R) if need_R else None
     gT = torch.zeros_like(T) if need_T else None
     with _on(verts):
-        _check(lib().ur_project_faces_backward(_ptr(verts, torch.float32), _ptr(faces, torch.int32),
+        _check(lib().ur_project_faces_backward(_ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
                                                _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F,
                                                _ptr(grad_face_verts, torch.float32), _ptr(gv, None, True),
                                                _ptr(gR, None, True), _ptr(gT, None, True), _stream(verts)),

@@ -1,0 +1,86 @@
+"""torch.autograd glue around the C ABI (unicorn_amd.native).  One Function per native stage, each honouring
+ctx.needs_input_grad so that the pose step (grads to R, T only) and the 3D step (grads to verts / texture only) of
+the reference's alternate optimisation (unicorn.py:226-230) skip the work they do not need."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import native
+
+
+class _ProjectFaces(Function):
+    """world verts -> NDC face corners (ur_project_faces); replaces MeshRasterizer.transform + the faces gather."""
+
+    @staticmethod
+    def forward(ctx, verts, faces, R, T, sx, sy):
+        verts, R, T = verts.contiguous(), R.contiguous(), T.contiguous()
+        ctx.save_for_backward(verts, faces, R, T)
+        ctx.scale = (sx, sy)
+        return native.project_faces(verts, faces, R, T, sx, sy)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_face_verts):
+        verts, faces, R, T = ctx.saved_tensors
+        need_v, _, need_R, need_T = ctx.needs_input_grad[:4]
+        gv, gR, gT = native.project_faces_backward(verts, faces, R, T, ctx.scale[0], ctx.scale[1],
+                                                   grad_face_verts.contiguous(), need_v, need_R, need_T)
+        return gv, None, gR, gT, None, None
+
+
+class _Rasterize(Function):
+    """ur_rasterize_meshes / ur_rasterize_meshes_backward; mirrors pytorch3d's _RasterizeFaceVerts."""
+
+    @staticmethod
+    def forward(ctx, face_verts, first, nfaces, image_size, blur_radius, K, clip, cull):
+        face_verts = face_verts.contiguous()
+        p2f, zbuf, bary, dists = native.rasterize_meshes(face_verts, first, nfaces, image_size, blur_radius, K, clip,
+                                                         cull)
+        ctx.save_for_backward(face_verts, p2f)
+        ctx.clip = clip
+        ctx.mark_non_differentiable(p2f)
+        return p2f, zbuf, bary, dists
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, _g_p2f, g_zbuf, g_bary, g_dists):
+        face_verts, p2f = ctx.saved_tensors
+        c = lambda g: None if g is None else g.contiguous()
+        gfv = native.rasterize_meshes_backward(face_verts, p2f, c(g_zbuf), c(g_bary), c(g_dists), ctx.clip)
+        return gfv, None, None, None, None, None, None, None
+
+
+class _ShadeBlend(Function):
+    """ur_shade_blend / ur_shade_blend_backward: TexturesUV sampling + ambient + layered_rgb_blend in one kernel."""
+
+    @staticmethod
+    def forward(ctx, bary, dists, maps, p2f, face_uvs, shared, first, sigma, background, ambient, mode):
+        bary, dists, maps = bary.contiguous(), dists.contiguous(), maps.contiguous()
+        ctx.save_for_backward(bary, dists, maps, p2f, face_uvs, first)
+        ctx.cfg = (shared, sigma, background, ambient, mode)
+        return native.shade_blend(p2f, bary, dists, maps, face_uvs, shared, first, sigma, background, ambient, mode)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_image):
+        bary, dists, maps, p2f, face_uvs, first = ctx.saved_tensors
+        shared, sigma, background, ambient, mode = ctx.cfg
+        need_bary, need_dists, need_maps = ctx.needs_input_grad[:3]
+        gmaps, gbary, gdists = native.shade_blend_backward(grad_image.contiguous(), p2f, bary, dists, maps, face_uvs,
+                                                           shared, first, sigma, background, ambient, mode, need_maps)
+        return (gbary if need_bary else None, gdists if need_dists else None, gmaps, None, None, None, None, None,
+                None, None, None)
+
+
+def project_faces(verts, faces, R, T, sx, sy):
+    return _ProjectFaces.apply(verts, faces, R, T, float(sx), float(sy))
+
+
+def rasterize(face_verts, first, nfaces, image_size, blur_radius, K, clip, cull=False):
+    return _Rasterize.apply(face_verts, first, nfaces, tuple(image_size), float(blur_radius), int(K), bool(clip),
+                            bool(cull))
+
+
+def shade_blend(p2f, bary, dists, maps, face_uvs, shared, first, sigma, background, ambient, mode):
+    return _ShadeBlend.apply(bary, dists, maps, p2f, face_uvs, bool(shared), first, float(sigma), tuple(background),
+                             None if ambient is None else tuple(ambient), int(mode))

@@ -1,0 +1,296 @@
+"""Drop-in for the reference's `Renderer` (src/model/renderer.py:25-116): same constructor kwargs, same
+`forward(meshes, R, T, viz_purpose=False) -> (N,4,H,W)`, `to`, `compute_vertex_visibility`, `update_lights`,
+`reset_default_lights`, `init_kwargs`, `.cameras`, `.lights`, `.renderer`, `.viz_renderer.rasterizer`.
+
+Everything numeric runs in the hand-written HIP kernels behind include/unicorn_render.h; this file only composes them.
+"""
+from copy import deepcopy
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import native, ops
+from .cameras import FoVPerspectiveCameras, PerspectiveCameras
+from .structures import Meshes, TexturesUV, TexturesVertex  # noqa: F401  (re-exported for callers)
+
+LAYERED_SHADER = True
+SHADING_TYPE = 'raw'
+VIZ_IMG_SIZE = 256
+
+
+class BlendParams:
+    def __init__(self, sigma=1e-4, gamma=1e-4, background_color=(1.0, 1.0, 1.0)):
+        self.sigma, self.gamma, self.background_color = sigma, gamma, background_color
+
+
+class RasterizationSettings:
+    def __init__(self, image_size=256, blur_radius=0.0, faces_per_pixel=1, perspective_correct=False,
+                 clip_barycentric_coords=None, cull_backfaces=False, **unused):
+        self.image_size = (image_size, image_size) if isinstance(image_size, int) else tuple(image_size)
+        self.blur_radius, self.faces_per_pixel = float(blur_radius), int(faces_per_pixel)
+        self.perspective_correct, self.cull_backfaces = perspective_correct, cull_backfaces
+        # pytorch3d: clip_barycentric_coords defaults to blur_radius > 0
+        self.clip_barycentric_coords = (self.blur_radius > 0.0) if clip_barycentric_coords is None \
+            else clip_barycentric_coords
+
+
+class Fragments:
+    """pix_to_face (packed indices, -1 = empty), zbuf, bary_coords, dists, all (N,H,W,K[,3]).  The kernels keep
+    int32 indices; `.pix_to_face` widens to int64 on first use (what pytorch3d hands to callers, renderer.py:108)."""
+
+    def __init__(self, pix_to_face_i32, zbuf, bary_coords, dists):
+        self.pix_to_face_i32, self.zbuf, self.bary_coords, self.dists = pix_to_face_i32, zbuf, bary_coords, dists
+        self._p2f64 = None
+
+    @property
+    def pix_to_face(self):
+        if self._p2f64 is None:
+            self._p2f64 = self.pix_to_face_i32.long()
+        return self._p2f64
+
+
+class AmbientLights:
+    """Ambient-only lighting (reference: pytorch3d_monkey.py:7-26); colour (1,1,1) leaves textures untouched."""
+
+    def __init__(self, ambient_color=((1.0, 1.0, 1.0),), device='cpu'):
+        self.ambient_color = ambient_color
+        self.device = device
+
+    def to(self, device):
+        self.device = device
+        return self
+
+
+class DirectionalLights(AmbientLights):
+    def __init__(self, ambient_color=((0.5, 0.5, 0.5),), diffuse_color=((0.3, 0.3, 0.3),),
+                 specular_color=((0.2, 0.2, 0.2),), direction=((0, 1, 0),), device='cpu'):
+        super().__init__(ambient_color, device)
+        self.diffuse_color, self.specular_color, self.direction = diffuse_color, specular_color, direction
+
+
+class PointLights(AmbientLights):
+    def __init__(self, ambient_color=((0.5, 0.5, 0.5),), diffuse_color=((0.3, 0.3, 0.3),),
+                 specular_color=((0.2, 0.2, 0.2),), location=((0, 1, 0),), device='cpu'):
+        super().__init__(ambient_color, device)
+        self.diffuse_color, self.specular_color, self.location = diffuse_color, specular_color, location
+
+
+def _rgb3(c):
+    """colour given as tuple / nested list / tensor -> 3 python floats, without touching the GPU stream unless the
+    caller stored a device tensor"""
+    t = torch.as_tensor(c, dtype=torch.float32).detach().cpu().flatten()
+    assert t.numel() == 3, "colour must have 3 components"
+    return tuple(float(v) for v in t)
+
+
+class MeshRasterizer(nn.Module):
+    """meshes + (R, T) -> Fragments.  Replaces pytorch3d MeshRasterizer (transform + rasterize_meshes)."""
+
+    def __init__(self, cameras=None, raster_settings=None):
+        super().__init__()
+        self.cameras = cameras
+        self.raster_settings = raster_settings if raster_settings is not None else RasterizationSettings()
+        self._idx_cache = {}
+
+    def to(self, device):
+        if self.cameras is not None:
+            self.cameras = self.cameras.to(device)
+        return self
+
+    def _mesh_index(self, N, F, device):
+        key = (N, F, str(device))
+        if key not in self._idx_cache:
+            first = torch.arange(N, dtype=torch.int64, device=device) * F
+            self._idx_cache[key] = (first, torch.full((N,), F, dtype=torch.int64, device=device))
+        return self._idx_cache[key]
+
+    def transform(self, meshes, R, T):
+        """-> face_verts (sum F_n, 3, 3) in NDC (z = view depth), mesh_first_face, mesh_num_faces"""
+        sx, sy = self.cameras.focal_scale()
+        if meshes.equisized:
+            verts, faces = meshes.verts_padded(), meshes.faces_padded()
+            N, Fn = faces.shape[:2]
+            faces = faces[0] if faces.stride(0) == 0 else faces
+            face_verts = ops.project_faces(verts.float(), faces.contiguous(), R.float(), T.float(), sx, sy)
+            first, nf = self._mesh_index(N, Fn, verts.device)
+            return face_verts, first, nf
+        # heterogeneous batch: plain tensor ops on the packed representation (not the reference's case)
+        idx = meshes.verts_packed_to_mesh_idx()
+        v = meshes.verts_packed()
+        view = torch.bmm(v[:, None], R[idx])[:, 0] + T[idx]
+        z = view[:, 2]
+        ndc = torch.stack([sx * view[:, 0] / z, sy * view[:, 1] / z, z], -1)
+        return ndc[meshes.faces_packed()], meshes.mesh_to_faces_packed_first_idx(), meshes.num_faces_per_mesh()
+
+    def forward(self, meshes, R=None, T=None, **kwargs):
+        rs = kwargs.get("raster_settings", self.raster_settings)
+        face_verts, first, nf = self.transform(meshes, R, T)
+        p2f, zbuf, bary, dists = ops.rasterize(face_verts, first, nf, rs.image_size, rs.blur_radius,
+                                               rs.faces_per_pixel, rs.clip_barycentric_coords, rs.cull_backfaces)
+        frag = Fragments(p2f, zbuf, bary, dists)
+        frag.mesh_first_face = first
+        return frag
+
+
+class LayeredShader(nn.Module):
+    """Reference: LayeredShader (renderer.py:127-172) + layered_rgb_blend (:175-202)."""
+
+    def __init__(self, device='cpu', cameras=None, lights=None, materials=None, blend_params=None, clip_inside=True,
+                 shading_type='raw', debug=False):
+        super().__init__()
+        self.lights = lights if lights is not None else AmbientLights()
+        self.materials, self.cameras = materials, cameras
+        self.blend_params = blend_params if blend_params is not None else BlendParams()
+        self.clip_inside, self.shading_type, self.debug = clip_inside, shading_type, debug
+        if shading_type not in ('raw', 'phong', 'flat', 'gouraud'):
+            raise NotImplementedError
+        if shading_type != 'raw':
+            raise NotImplementedError("only shading_type='raw' (the training setting, renderer.py:21) is built; "
+                                      "phong/flat/gouraud serve the eye_light GIF viz only")
+        if debug:
+            raise NotImplementedError("debug=True returns the blend's intermediates; not built")
+
+    def to(self, device):
+        if self.cameras is not None:
+            self.cameras = self.cameras.to(device)
+        self.lights = self.lights.to(device)
+        return self
+
+    def blend_mode(self, blend_params):
+        if blend_params.sigma == 0:
+            return native.BLEND_HARD
+        return native.BLEND_CLIP_INSIDE if self.clip_inside else native.BLEND_SIGMOID
+
+    def forward(self, fragments, meshes, **kwargs):
+        bp = kwargs.get("blend_params", self.blend_params)
+        tex = meshes.textures
+        if not isinstance(tex, TexturesUV):
+            raise NotImplementedError("LayeredShader needs TexturesUV (TexturesVertex: see shading.sample_textures)")
+        ambient = _rgb3(self.lights.ambient_color)
+        face_uvs, shared = tex.faces_verts_uvs()
+        return ops.shade_blend(fragments.pix_to_face_i32, fragments.bary_coords, fragments.dists,
+                               tex.maps_padded().float(), face_uvs.float(), shared, fragments.mesh_first_face,
+                               bp.sigma, _rgb3(bp.background_color), None if ambient == (1.0, 1.0, 1.0) else ambient,
+                               self.blend_mode(bp))
+
+
+class MeshRenderer(nn.Module):
+    def __init__(self, rasterizer, shader):
+        super().__init__()
+        self.rasterizer, self.shader = rasterizer, shader
+
+    def to(self, device):
+        self.rasterizer.to(device)
+        self.shader.to(device)
+        return self
+
+    def forward(self, meshes, **kwargs):
+        fragments = self.rasterizer(meshes, **kwargs)
+        return self.shader(fragments, meshes, **kwargs)
+
+
+class VizMeshRenderer(MeshRenderer):
+    """Renderer for visualization, with anti-aliasing (2x supersampling + average pooling; renderer.py:119-124)"""
+
+    @torch.no_grad()
+    def __call__(self, *input, **kwargs):
+        res = super().__call__(*input, **kwargs)
+        return F.avg_pool2d(res, kernel_size=2, stride=2)
+
+
+class Renderer(nn.Module):
+    def __init__(self, img_size, **kwargs):
+        super().__init__()
+        img_size = (img_size, img_size) if isinstance(img_size, int) else img_size
+        self._init_kwargs = deepcopy(kwargs)
+        self.init_cameras(**kwargs.get('cameras', {}))
+        self.init_lights(**kwargs.get('lights', {}))
+        blend_kwargs = {'sigma': kwargs.get('sigma', 1e-4),
+                        'background_color': kwargs.get('background_color', (1, 1, 1))}
+        n_faces = kwargs.get('faces_per_pixel', 25)
+        blend_params = BlendParams(**blend_kwargs)
+        s_kwargs = {'cameras': self.cameras, 'lights': self.lights, 'blend_params': blend_params,
+                    'debug': kwargs.get('debug', False)}
+        if kwargs.get('layered_shader', LAYERED_SHADER):
+            shader_cls = LayeredShader
+            s_kwargs['clip_inside'] = kwargs.get('clip_inside', True)
+            s_kwargs['shading_type'] = kwargs.get('shading_type', SHADING_TYPE)
+        else:
+            raise NotImplementedError("layered_shader=False (SoftPhongShaderPlus / softmax blend) is not built yet")
+
+        # approximative differentiable renderer for training (renderer.py:45-49)
+        raster_settings = RasterizationSettings(image_size=img_size,
+                                                blur_radius=np.log(1. / 1e-4 - 1.) * blend_params.sigma,
+                                                faces_per_pixel=n_faces, perspective_correct=False)
+        self.renderer = MeshRenderer(MeshRasterizer(cameras=self.cameras, raster_settings=raster_settings),
+                                     shader_cls(**s_kwargs))
+
+        # exact anti-aliased rendering for visualization (renderer.py:51-57)
+        viz_size = kwargs.get('viz_size', (VIZ_IMG_SIZE, VIZ_IMG_SIZE))
+        s_kwargs['blend_params'] = BlendParams(background_color=blend_kwargs['background_color'], sigma=0)
+        raster_settings = RasterizationSettings(image_size=(viz_size[0] * 2, viz_size[1] * 2), blur_radius=0.0,
+                                                faces_per_pixel=1, perspective_correct=False)
+        self.viz_renderer = VizMeshRenderer(MeshRasterizer(cameras=self.cameras, raster_settings=raster_settings),
+                                            shader_cls(**s_kwargs))
+
+    def init_cameras(self, **kwargs):
+        kwargs = deepcopy(kwargs)
+        name = kwargs.pop('name', 'fov')
+        cam_cls = {'fov': FoVPerspectiveCameras, 'perspective': PerspectiveCameras}[name]
+        self.cameras = cam_cls(**kwargs)
+
+    def init_lights(self, **kwargs):
+        kwargs = deepcopy(kwargs)
+        name = kwargs.pop('name', 'ambient')
+        light_cls = {'ambient': AmbientLights, 'directional': DirectionalLights, 'point': PointLights}[name]
+        self.lights = light_cls(**kwargs)
+        if name == 'directional':
+            self.lights._direction = self.lights.direction
+            self.lights._ambient_color = self.lights.ambient_color
+            self.lights._diffuse_color = self.lights.diffuse_color
+            self.lights._specular_color = self.lights.specular_color
+
+    @property
+    def init_kwargs(self):
+        return deepcopy(self._init_kwargs)
+
+    def forward(self, meshes, R, T, viz_purpose=False):
+        return self.viz_renderer(meshes, R=R, T=T) if viz_purpose else self.renderer(meshes, R=R, T=T)  # BCHW
+
+    def to(self, device):
+        super().to(device)
+        self.renderer = self.renderer.to(device)
+        self.viz_renderer = self.viz_renderer.to(device)
+        return self
+
+    def update_lights(self, direction=None, ka=None, kd=None, ks=None):
+        if direction is not None:
+            self.lights.direction = direction
+        if ka is not None:
+            self.lights.ambient_color = ka
+        if kd is not None:
+            self.lights.diffuse_color = kd
+        if ks is not None:
+            self.lights.specular_color = ks
+
+    def reset_default_lights(self):
+        self.lights.direction = self.lights._direction
+        self.lights.ambient_color = self.lights._ambient_color
+        self.lights.diffuse_color = self.lights._diffuse_color
+        self.lights.specular_color = self.lights._specular_color
+
+    @torch.no_grad()
+    def compute_vertex_visibility(self, meshes, R, T):
+        """(N,V) bool: vertices of faces that own at least one pixel of the hard 2x-supersampled raster
+        (renderer.py:105-116)."""
+        fragments = self.viz_renderer.rasterizer(meshes, R=R, T=T)
+        p2f = fragments.pix_to_face_i32
+        packed_faces = meshes.faces_packed()
+        n_verts = meshes.verts_packed().shape[0]
+        face_visible = torch.zeros(packed_faces.shape[0] + 1, dtype=torch.bool, device=p2f.device)
+        face_visible[(p2f.flatten() + 1).long()] = True  # slot 0 collects the -1 entries
+        vis = torch.zeros(n_verts, dtype=torch.bool, device=p2f.device)
+        vis[packed_faces[face_visible[1:]].flatten()] = True
+        return vis.view(len(meshes), -1)

@@ -1,0 +1,368 @@
+"""Batched mesh / texture containers with the method surface the reference's callers use on pytorch3d's `Meshes`,
+`TexturesUV` and `TexturesVertex` (unicorn.py:262-266,283,350,389,407,499,512; utils/mesh.py:21-139;
+renderer.py:109-110,273).  Own implementation: tensors are kept padded (N,V,3)/(N,F,3) when every mesh of the batch
+has the same size (the reference's only case: one icosphere topology), which is also the layout the HIP kernels read.
+"""
+import torch
+
+
+def _as_list(x):
+    if torch.is_tensor(x):
+        if x.dim() != 3:
+            raise ValueError("padded tensors must be (N, M, 3)")
+        return list(x.unbind(0))
+    return list(x)
+
+
+class TexturesUV:
+    """maps (N,Ht,Wt,C) in [0,1]; faces_uvs (N,F,3) int64 indices into verts_uvs (N,V,2).  Sampling follows
+    pytorch3d 0.6.2: bilinear, align_corners=True, padding_mode='border', v axis flipped."""
+
+    def __init__(self, maps, faces_uvs, verts_uvs, padding_mode="border", align_corners=True, sampling_mode="bilinear"):
+        if padding_mode != "border" or not align_corners or sampling_mode != "bilinear":
+            raise NotImplementedError("only bilinear / align_corners=True / border padding (pytorch3d defaults)")
+        if not torch.is_tensor(maps):
+            maps = torch.stack(list(maps))
+        if not torch.is_tensor(faces_uvs):
+            faces_uvs = torch.stack(list(faces_uvs))
+        if not torch.is_tensor(verts_uvs):
+            verts_uvs = torch.stack(list(verts_uvs))
+        if maps.dim() != 4 or faces_uvs.dim() != 3 or verts_uvs.dim() != 3:
+            raise ValueError("expected maps (N,H,W,C), faces_uvs (N,F,3), verts_uvs (N,V,2)")
+        self._maps, self._faces_uvs, self._verts_uvs = maps, faces_uvs, verts_uvs
+        self._num_faces_per_mesh = [faces_uvs.shape[1]] * len(maps)
+        self.device = maps.device
+
+    def __len__(self):
+        return self._maps.shape[0]
+
+    def maps_padded(self):
+        return self._maps
+
+    def faces_uvs_padded(self):
+        return self._faces_uvs
+
+    def verts_uvs_padded(self):
+        return self._verts_uvs
+
+    def maps_list(self):
+        return list(self._maps.unbind(0))
+
+    def _shared_tables(self):
+        """True when faces_uvs / verts_uvs are batch-expanded views of one table (unicorn.py:283 builds them with
+        .expand): one (F,3,2) face-UV table then serves every mesh."""
+        return self._faces_uvs.stride(0) == 0 and self._verts_uvs.stride(0) == 0
+
+    def faces_verts_uvs(self):
+        """(face_uvs, shared): (F,3,2) with shared=True, else packed (N*F,3,2)."""
+        if self._shared_tables() or len(self) == 1:
+            return self._verts_uvs[0][self._faces_uvs[0]].contiguous(), True
+        idx = self._faces_uvs  # (N,F,3)
+        N, F = idx.shape[:2]
+        out = torch.gather(self._verts_uvs, 1, idx.reshape(N, F * 3, 1).expand(-1, -1, 2)).view(N * F, 3, 2)
+        return out.contiguous(), False
+
+    def detach(self):
+        return TexturesUV(self._maps.detach(), self._faces_uvs.detach(), self._verts_uvs.detach())
+
+    def clone(self):
+        return TexturesUV(self._maps.clone(), self._faces_uvs.clone(), self._verts_uvs.clone())
+
+    def to(self, device):
+        return TexturesUV(self._maps.to(device), self._faces_uvs.to(device), self._verts_uvs.to(device))
+
+    def extend(self, N):
+        r = lambda t: t.repeat_interleave(N, dim=0)
+        return TexturesUV(r(self._maps), r(self._faces_uvs), r(self._verts_uvs))
+
+    def __getitem__(self, index):
+        index = [index] if isinstance(index, int) else index
+        return TexturesUV(self._maps[index], self._faces_uvs[index], self._verts_uvs[index])
+
+
+class TexturesVertex:
+    """Per-vertex features (N,V,C), interpolated with the barycentrics."""
+
+    def __init__(self, verts_features):
+        if not torch.is_tensor(verts_features):
+            verts_features = torch.stack(list(verts_features))
+        if verts_features.dim() != 3:
+            raise ValueError("verts_features must be (N,V,C)")
+        self._feat = verts_features
+        self._num_verts_per_mesh = [verts_features.shape[1]] * len(verts_features)
+        self.device = verts_features.device
+
+    def __len__(self):
+        return self._feat.shape[0]
+
+    def verts_features_padded(self):
+        return self._feat
+
+    def verts_features_packed(self):
+        return self._feat.reshape(-1, self._feat.shape[-1])
+
+    def detach(self):
+        return TexturesVertex(self._feat.detach())
+
+    def clone(self):
+        return TexturesVertex(self._feat.clone())
+
+    def to(self, device):
+        return TexturesVertex(self._feat.to(device))
+
+    def extend(self, N):
+        return TexturesVertex(self._feat.repeat_interleave(N, dim=0))
+
+    def __getitem__(self, index):
+        index = [index] if isinstance(index, int) else index
+        return TexturesVertex(self._feat[index])
+
+
+class Meshes:
+    """Batch of triangle meshes.  verts: list of (V_n,3) float tensors or a padded (N,V,3) tensor; faces likewise
+    (int64).  Autograd flows through the vertex tensors."""
+
+    def __init__(self, verts, faces, textures=None):
+        self._verts_list, self._faces_list = None, None
+        self._verts_padded, self._faces_padded = None, None
+        if torch.is_tensor(verts) and torch.is_tensor(faces):
+            if verts.dim() != 3 or faces.dim() != 3:
+                raise ValueError("padded verts / faces must be (N,V,3) / (N,F,3)")
+            self._verts_padded, self._faces_padded = verts, faces
+            self._N = verts.shape[0]
+            self._equisized = True  # padded input is taken as unpadded same-size meshes
+        else:
+            self._verts_list, self._faces_list = _as_list(verts), _as_list(faces)
+            self._N = len(self._verts_list)
+            if len(self._faces_list) != self._N:
+                raise ValueError("verts and faces must have the same batch size")
+            self._equisized = (len({v.shape[0] for v in self._verts_list}) <= 1 and
+                               len({f.shape[0] for f in self._faces_list}) <= 1)
+        self.textures = textures
+        self._cache = {}
+
+    # ---- basic ----------------------------------------------------------------------------------------------
+    def __len__(self):
+        return self._N
+
+    @property
+    def device(self):
+        return (self._verts_padded if self._verts_padded is not None else self._verts_list[0]).device
+
+    @property
+    def equisized(self):
+        return self._equisized
+
+    def isempty(self):
+        return self._N == 0 or self.verts_packed().shape[0] == 0
+
+    def verts_list(self):
+        if self._verts_list is None:
+            self._verts_list = list(self._verts_padded.unbind(0))
+        return self._verts_list
+
+    def faces_list(self):
+        if self._faces_list is None:
+            self._faces_list = list(self._faces_padded.unbind(0))
+        return self._faces_list
+
+    def num_verts_per_mesh(self):
+        return torch.tensor([v.shape[0] for v in self.verts_list()], dtype=torch.int64, device=self.device)
+
+    def num_faces_per_mesh(self):
+        return torch.tensor([f.shape[0] for f in self.faces_list()], dtype=torch.int64, device=self.device)
+
+    def verts_padded(self):
+        if self._verts_padded is None:
+            if self._equisized:
+                self._verts_padded = torch.stack(self._verts_list) if self._N else torch.zeros(0, 0, 3)
+            else:
+                V = max(v.shape[0] for v in self._verts_list)
+                self._verts_padded = torch.stack([torch.nn.functional.pad(v, (0, 0, 0, V - v.shape[0]))
+                                                  for v in self._verts_list])
+        return self._verts_padded
+
+    def faces_padded(self):
+        if self._faces_padded is None:
+            if self._equisized:
+                self._faces_padded = torch.stack(self._faces_list) if self._N else torch.zeros(0, 0, 3).long()
+            else:
+                F = max(f.shape[0] for f in self._faces_list)
+                self._faces_padded = torch.stack([torch.nn.functional.pad(f, (0, 0, 0, F - f.shape[0]), value=-1)
+                                                  for f in self._faces_list])
+        return self._faces_padded
+
+    def verts_packed(self):
+        if self._equisized:
+            return self.verts_padded().reshape(-1, 3)
+        return torch.cat(self.verts_list(), 0)
+
+    def mesh_to_verts_packed_first_idx(self):
+        nv = self.num_verts_per_mesh()
+        return torch.cumsum(nv, 0) - nv
+
+    def mesh_to_faces_packed_first_idx(self):
+        nf = self.num_faces_per_mesh()
+        return torch.cumsum(nf, 0) - nf
+
+    def faces_packed(self):
+        if "faces_packed" not in self._cache:
+            first = self.mesh_to_verts_packed_first_idx()
+            if self._equisized:
+                fp = (self.faces_padded() + first.view(-1, 1, 1)).reshape(-1, 3)
+            else:
+                fp = torch.cat([f + o for f, o in zip(self.faces_list(), first)], 0)
+            self._cache["faces_packed"] = fp
+        return self._cache["faces_packed"]
+
+    def verts_packed_to_mesh_idx(self):
+        return torch.repeat_interleave(torch.arange(self._N, device=self.device), self.num_verts_per_mesh())
+
+    def faces_packed_to_mesh_idx(self):
+        return torch.repeat_interleave(torch.arange(self._N, device=self.device), self.num_faces_per_mesh())
+
+    def get_mesh_verts_faces(self, index):
+        return self.verts_list()[index], self.faces_list()[index]
+
+    def _edges(self):
+        if "edges" not in self._cache:
+            f = self.faces_packed()
+            e = torch.cat([f[:, [1, 2]], f[:, [2, 0]], f[:, [0, 1]]], 0)  # edge i is opposite to corner i
+            e, _ = e.sort(dim=1)
+            V = max(int(self.verts_packed().shape[0]), 1)
+            key = e[:, 0] * V + e[:, 1]
+            uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
+            edges = torch.stack([uniq // V, uniq % V], 1)
+            F = f.shape[0]
+            self._cache["edges"] = (edges, inv.view(3, F).t().contiguous())
+        return self._cache["edges"]
+
+    def edges_packed(self):
+        return self._edges()[0]
+
+    def faces_packed_to_edges_packed(self):
+        return self._edges()[1]
+
+    # ---- transforms -----------------------------------------------------------------------------------------
+    def _new_verts(self, verts_padded=None, verts_list=None, textures="same"):
+        tex = self.textures if textures == "same" else textures
+        if verts_padded is not None:
+            faces = self._faces_padded if self._faces_padded is not None else self.faces_padded()
+            m = Meshes(verts_padded, faces, tex)
+        else:
+            m = Meshes(verts_list, self.faces_list(), tex)
+        for k in ("faces_packed", "edges"):
+            if k in self._cache:
+                m._cache[k] = self._cache[k]
+        return m
+
+    def _assign(self, other):
+        self._verts_list, self._verts_padded = other._verts_list, other._verts_padded
+        return self
+
+    def offset_verts(self, offsets_packed):
+        """offsets (sum V_n, 3) packed, or a (3,) vector"""
+        if offsets_packed.shape == (3,):
+            offsets_packed = offsets_packed.expand(self.verts_packed().shape[0], 3)
+        if self._equisized:
+            return self._new_verts(verts_padded=self.verts_padded() + offsets_packed.view(self.verts_padded().shape))
+        nv = [v.shape[0] for v in self.verts_list()]
+        return self._new_verts(verts_list=[v + o for v, o in zip(self.verts_list(), offsets_packed.split(nv))])
+
+    def offset_verts_(self, offsets_packed):
+        return self._assign(self.offset_verts(offsets_packed))
+
+    def scale_verts(self, scale):
+        """scale: float, (N,) or (N,3) tensor (unicorn.py:92,266 pass (1,3) / (B,3))"""
+        if not torch.is_tensor(scale):
+            scale = torch.full((self._N,), float(scale), device=self.device)
+        if scale.shape[0] != self._N:
+            scale = scale.expand(self._N, *scale.shape[1:])
+        if self._equisized:
+            s = scale.view(self._N, 1, -1) if scale.dim() == 2 else scale.view(self._N, 1, 1)
+            return self._new_verts(verts_padded=self.verts_padded() * s)
+        return self._new_verts(verts_list=[scale[i] * v for i, v in enumerate(self.verts_list())])
+
+    def scale_verts_(self, scale):
+        return self._assign(self.scale_verts(scale))
+
+    def update_padded(self, new_verts_padded):
+        return self._new_verts(verts_padded=new_verts_padded)
+
+    def detach(self):
+        tex = self.textures.detach() if self.textures is not None else None
+        if self._equisized:
+            return self._new_verts(verts_padded=self.verts_padded().detach(), textures=tex)
+        return self._new_verts(verts_list=[v.detach() for v in self.verts_list()], textures=tex)
+
+    def clone(self):
+        tex = self.textures.clone() if self.textures is not None else None
+        return Meshes([v.clone() for v in self.verts_list()], [f.clone() for f in self.faces_list()], tex)
+
+    def to(self, device):
+        tex = self.textures.to(device) if self.textures is not None else None
+        if self._equisized and self._N:
+            return Meshes(self.verts_padded().to(device), self.faces_padded().to(device), tex)
+        return Meshes([v.to(device) for v in self.verts_list()], [f.to(device) for f in self.faces_list()], tex)
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def extend(self, N):
+        """N copies of every mesh, repeat_interleave order (m0, m0, ..., m1, m1, ...)"""
+        tex = self.textures.extend(N) if self.textures is not None else None
+        if self._equisized and self._N:
+            return Meshes(self.verts_padded().repeat_interleave(N, 0), self.faces_padded().repeat_interleave(N, 0), tex)
+        verts, faces = [], []
+        for v, f in zip(self.verts_list(), self.faces_list()):
+            verts += [v.clone() for _ in range(N)]
+            faces += [f.clone() for _ in range(N)]
+        return Meshes(verts, faces, tex)
+
+    def __getitem__(self, index):
+        if isinstance(index, int):
+            index = [index]
+        tex = self.textures[index] if self.textures is not None else None
+        if isinstance(index, slice):
+            return Meshes(self.verts_list()[index], self.faces_list()[index], tex)
+        if torch.is_tensor(index):
+            index = index.nonzero().flatten().tolist() if index.dtype == torch.bool else index.tolist()
+        return Meshes([self.verts_list()[i] for i in index], [self.faces_list()[i] for i in index], tex)
+
+    def sample_textures(self, fragments):
+        from .shading import sample_textures
+        return sample_textures(self, fragments)
+
+
+def join_meshes_as_batch(meshes):
+    verts, faces = [], []
+    for m in meshes:
+        verts += m.verts_list()
+        faces += m.faces_list()
+    return Meshes(verts, faces)
+
+
+def repeat(mesh, N):
+    """N copies in torch `repeat` (tile) order -- the convention of the reference's utils/mesh.py:43-71 (candidate
+    poses are K-major, unicorn.py:295-304).  One tensor op per field instead of K*B clones."""
+    assert N >= 1
+    if N == 1:
+        return mesh
+    tex = mesh.textures
+    if isinstance(tex, TexturesVertex):
+        new_tex = TexturesVertex(tex.verts_features_padded().repeat(N, 1, 1))
+    elif isinstance(tex, TexturesUV):
+        shared = tex._shared_tables()
+        rep = (lambda t: t[:1].expand(len(tex) * N, -1, -1)) if shared else (lambda t: t.repeat(N, 1, 1))
+        new_tex = TexturesUV(tex.maps_padded().repeat(N, 1, 1, 1), rep(tex.faces_uvs_padded()),
+                             rep(tex.verts_uvs_padded()))
+    elif tex is None:
+        new_tex = None
+    else:
+        raise NotImplementedError
+    if mesh.equisized:
+        return Meshes(mesh.verts_padded().repeat(N, 1, 1), mesh.faces_padded().repeat(N, 1, 1), new_tex)
+    return Meshes(mesh.verts_list() * N, mesh.faces_list() * N, new_tex)
