@@ -1,0 +1,180 @@
+"""bench.py -- rendered images/s, forward + backward, through the `Renderer` drop-in.
+
+Workload (BASELINE.json metric): B=32 textured level-3 icospheres (642 V / 1280 F) per GPU,
+128x128, faces_per_pixel K=50, sigma=1e-4, 64x64 UV textures, FoV-30 camera, fixed random cotangent; gradients to
+vertices, textures, R and T.  One "step" = one Renderer.forward + one backward of that batch.  Inputs live in HBM
+before the timed region.  With N>1 GPUs every rank renders its own batch (weak scaling, no collective on the data
+path -- images are independent); the timed region is bracketed by barrier + synchronize and the max over ranks is used.
+
+Prints ONE JSON line.  `roofline` prices the dominant kernel (the rasterizer launch) against HBM; `cpu_baseline` times
+the oracle's CPU restatement (oracle/, test infrastructure) on the host cores for a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from unicorn_amd import native, synth  # noqa: E402
+from unicorn_amd.renderer import Renderer  # noqa: E402
+from unicorn_amd.structures import Meshes, TexturesUV  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
+
+WORKLOADS = {
+    # name: batch per GPU, icosphere level, image, K, texture
+    "C4_B32_128x128_K50_ico3": dict(B=32, level=3, img=128, K=50, tex=64),
+    "C2_B32_64x64_K50_ico3": dict(B=32, level=3, img=64, K=50, tex=64),
+    "C4b_B64_128x128_K50_ico4": dict(B=64, level=4, img=128, K=50, tex=64),
+}
+
+
+def path_bytes_per_image(H, W, K, F, Ht, Wt):
+    """fragments written once (24 B) and read once (20 B) + RGBA out/grad + faces + texture."""
+    return 44 * H * W * K + 32 * H * W + 108 * F + 24 * Ht * Wt
+
+
+def raster_bytes_per_image(H, W, K, F):
+    """dominant kernel (ur_rasterize_meshes): fragment write 24 B per (pixel, k) + face corners read once"""
+    return 24 * H * W * K + 36 * F
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    from oracle import orc
+    s = float(1.0 / np.tan(np.deg2rad(15.0)))
+    n = 4
+    sc = synth.make_scene(n, level=cfg["level"], tex_size=cfg["tex"], seed=0)
+    args = lambda m: (sc["verts"][:m].numpy(), sc["faces"].numpy(), sc["R"][:m].numpy(), sc["T"][:m].numpy(),
+                      sc["maps"][:m].numpy(), sc["verts_uvs"][None].expand(m, -1, -1).numpy())
+    cot = np.random.RandomState(0).randn(n, 4, cfg["img"], cfg["img"]).astype(np.float32)
+    t0 = time.perf_counter()
+    orc.render_fwd_bwd(*args(1), H=cfg["img"], W=cfg["img"], K=cfg["K"], s=s, grad_image=cot[:1], n_threads=1)
+    t1 = time.perf_counter() - t0
+    m = int(max(1, min(n, seconds_budget / 2 / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    orc.render_fwd_bwd(*args(m), H=cfg["img"], W=cfg["img"], K=cfg["K"], s=s, grad_image=cot[:m], n_threads=1)
+    single = m / (time.perf_counter() - t0)
+    cores = min(16, os.cpu_count() or 1)  # the GPU box gives a 1-GPU job a 16-core share
+    big = synth.make_scene(cores * 2, level=cfg["level"], tex_size=cfg["tex"], seed=0)
+    bcot = np.random.RandomState(0).randn(cores * 2, 4, cfg["img"], cfg["img"]).astype(np.float32)
+    t0 = time.perf_counter()
+    orc.render_fwd_bwd(big["verts"].numpy(), big["faces"].numpy(), big["R"].numpy(), big["T"].numpy(),
+                       big["maps"].numpy(), big["verts_uvs"][None].expand(cores * 2, -1, -1).numpy(), H=cfg["img"],
+                       W=cfg["img"], K=cfg["K"], s=s, grad_image=bcot, n_threads=cores)
+    multi = cores * 2 / (time.perf_counter() - t0)
+    return {"value": round(multi, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "single_thread_value": round(single, 3),
+            "sample": f"{cores * 2} images of the same workload ({cfg['img']}x{cfg['img']}, K={cfg['K']}, "
+                      f"ico{cfg['level']}) fwd+bwd on {cores} threads (meshes split over threads); "
+                      f"{m} image(s) on 1 thread for single_thread_value; oracle/ C++ restatement of the "
+                      f"pytorch3d-style naive CPU rasterizer (pytorch3d itself is not available offline)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C4_B32_128x128_K50_ico3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    native.lib()
+
+    cfg = WORKLOADS[a.workload]
+    B, H, K = cfg["B"], cfg["img"], cfg["K"]
+    sc = synth.make_scene(B, level=cfg["level"], tex_size=cfg["tex"], seed=100 * rank, device=dev)
+    F = sc["faces"].shape[0]
+    rend = Renderer(H, cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=1e-4).to(dev)
+    verts = sc["verts"].requires_grad_(True)
+    maps = sc["maps"].requires_grad_(True)
+    R = sc["R"].requires_grad_(True)
+    T = sc["T"].requires_grad_(True)
+    fb, ub = sc["faces"][None].expand(B, -1, -1), sc["verts_uvs"][None].expand(B, -1, -1)
+    cot = torch.randn(B, 4, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+
+    def step():
+        for t in (verts, maps, R, T):
+            t.grad = None
+        meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))  # unicorn.py:262-266,283
+        img = rend(meshes, R, T)
+        img.backward(cot)
+        return img
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline leg: the same steps again with HIP events around every C-ABI call (rank 0 only)
+    result = None
+    if rank == 0:
+        native.enable_timing(True)
+        for _ in range(a.steps):
+            step()
+        per_call = native.timing_summary()
+        native.enable_timing(False)
+        dom = max(per_call, key=lambda k: per_call[k][1])
+        raster_ms = per_call["ur_rasterize_meshes"][1]
+        alg = B * raster_bytes_per_image(H, H, K, F)
+        achieved = alg / (raster_ms * 1e-3) / 1e9
+        ips = world * B * a.steps / elapsed
+        path_gbps = ips / world * path_bytes_per_image(H, H, K, F, cfg["tex"], cfg["tex"]) / 1e9
+        result = {
+            "metric": "rendered images/sec fwd+bwd (B=32, 128x128, K=50)", "value": round(ips, 2),
+            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": a.workload, "batch_per_gpu": B, "image": [H, H], "faces_per_pixel": K,
+                       "faces_per_mesh": F, "texture": [cfg["tex"], cfg["tex"]], "sigma": 1e-4,
+                       "grads": "verts+texture+R+T"},
+            "roofline": {"bound": "hbm", "kernel": "k_raster (ur_rasterize_meshes)", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms": round(raster_ms, 4), "dominant_call": dom},
+            "path_hbm": {"bytes_per_image": path_bytes_per_image(H, H, K, F, cfg["tex"], cfg["tex"]),
+                         "achieved_GBps_per_gpu": round(path_gbps, 2),
+                         "frac_of_peak": round(path_gbps / HBM_PEAK_GBPS, 4)},
+            "per_call_ms": {k: round(v[1], 4) for k, v in sorted(per_call.items())},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(cfg)
+            result["gpu_over_cpu"] = round(ips / result["cpu_baseline"]["value"], 1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

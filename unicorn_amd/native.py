@@ -58,6 +58,37 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed ({rc}): {lib().ur_last_error().decode()}")
 
 
+# ---- optional per-call device timing (bench.py's roofline leg): HIP events recorded on the launch stream around a
+# C-ABI call; nothing is recorded unless enabled, and nothing here synchronises.
+_timing = None
+
+
+def enable_timing(on=True):
+    global _timing
+    _timing = {} if on else None
+
+
+class _timed:
+    def __init__(self, name, t):
+        self.name, self.t = name, t
+
+    def __enter__(self):
+        if _timing is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.t.device))
+
+    def __exit__(self, *a):
+        if _timing is not None:
+            self.e1.record(torch.cuda.current_stream(self.t.device))
+            _timing.setdefault(self.name, []).append((self.e0, self.e1))
+
+
+def timing_summary():
+    """{call name: (launches, mean ms)}; synchronises."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in (_timing or {}).items()}
+
+
 def _ptr(t, dtype=None, allow_none=False):
     if t is None:
         if allow_none:
@@ -111,7 +142,7 @@ def project_faces(verts, faces, R, T, sx, sy):
     N, V = verts.shape[:2]
     F, fstride = _faces_layout(faces, N)
     out = torch.empty(N * F, 3, 3, dtype=torch.float32, device=verts.device)
-    with _on(verts):
+    with _on(verts), _timed("ur_project_faces", verts):
         _check(lib().ur_project_faces(_ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
                                       _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(out),
                                       _stream(verts)), "ur_project_faces")
@@ -124,7 +155,7 @@ def project_faces_backward(verts, faces, R, T, sx, sy, grad_face_verts, need_ver
     gv = torch.zeros_like(verts) if need_verts else None
     gR = torch.zeros_like(R) if need_R else None
     gT = torch.zeros_like(T) if need_T else None
-    with _on(verts):
+    with _on(verts), _timed("ur_project_faces_backward", verts):
         _check(lib().ur_project_faces_backward(_ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
                                                _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F,
                                                _ptr(grad_face_verts, torch.float32), _ptr(gv, None, True),
@@ -147,7 +178,7 @@ def rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, bl
     bary = torch.empty(N, H, W, K, 3, dtype=torch.float32, device=dev) if want_bary else None
     dists = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if want_dists else None
     ws = _workspace(NF, dev)
-    with _on(face_verts):
+    with _on(face_verts), _timed("ur_rasterize_meshes", face_verts):
         _check(lib().ur_rasterize_meshes(_ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64),
                                          _ptr(mesh_num_faces, torch.int64), N, NF, H, W, float(blur_radius), K,
                                          int(perspective_correct), int(clip_barycentric_coords), int(cull_backfaces),
@@ -161,7 +192,7 @@ def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, gra
                               perspective_correct=False):
     N, H, W, K = pix_to_face.shape
     gfv = torch.zeros_like(face_verts)
-    with _on(face_verts):
+    with _on(face_verts), _timed("ur_rasterize_meshes_backward", face_verts):
         _check(lib().ur_rasterize_meshes_backward(_ptr(face_verts, torch.float32), _ptr(pix_to_face, torch.int32),
                                                   _ptr(grad_zbuf, torch.float32, True),
                                                   _ptr(grad_bary, torch.float32, True),
@@ -180,7 +211,7 @@ def tile_faces(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_rad
     counts = torch.empty(N, TH, TW, dtype=torch.int32, device=dev)
     lists = torch.empty(N, TH, TW, cap, dtype=torch.int32, device=dev)
     ws = _workspace(NF, dev)
-    with _on(face_verts):
+    with _on(face_verts), _timed("ur_tile_faces", face_verts):
         _check(lib().ur_tile_faces(_ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64),
                                    _ptr(mesh_num_faces, torch.int64), N, NF, H, W, float(blur_radius),
                                    int(cull_backfaces), int(cap), _ptr(counts), _ptr(lists), _ptr(ws), ws.numel(),
@@ -197,7 +228,7 @@ def shade_blend(pix_to_face, bary, dists, maps, face_uvs, face_uvs_shared, mesh_
     N, H, W, K = pix_to_face.shape
     Ht, Wt = maps.shape[1:3]
     image = torch.empty(N, 4, H, W, dtype=torch.float32, device=maps.device)
-    with _on(maps):
+    with _on(maps), _timed("ur_shade_blend", maps):
         _check(lib().ur_shade_blend(_ptr(pix_to_face, torch.int32), _ptr(bary, torch.float32),
                                     _ptr(dists, torch.float32), _ptr(maps, torch.float32),
                                     _ptr(face_uvs, torch.float32), int(face_uvs_shared),
@@ -215,7 +246,7 @@ def shade_blend_backward(grad_image, pix_to_face, bary, dists, maps, face_uvs, f
     gmaps = torch.zeros_like(maps) if need_maps else None
     gbary = torch.empty_like(bary)
     gdists = torch.empty_like(dists)
-    with _on(maps):
+    with _on(maps), _timed("ur_shade_blend_backward", maps):
         _check(lib().ur_shade_blend_backward(_ptr(grad_image, torch.float32), _ptr(pix_to_face, torch.int32),
                                              _ptr(bary, torch.float32), _ptr(dists, torch.float32),
                                              _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32),
