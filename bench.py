@@ -41,9 +41,13 @@ def path_bytes_per_image(H, W, K, F, Ht, Wt):
     return 44 * H * W * K + 32 * H * W + 108 * F + 24 * Ht * Wt
 
 
-def raster_bytes_per_image(H, W, K, F):
-    """dominant kernel (ur_rasterize_meshes): fragment write 24 B per (pixel, k) + face corners read once"""
-    return 24 * H * W * K + 36 * F
+def kernel_bytes_per_image(call, H, W, K, F, Ht, Wt):
+    """The forward / backward launch's share of SURVEY.md 8(d)'s per-image figure: the forward owns the fragment
+    write (24 B per (pixel, k)), the RGBA image, one pass over the faces and the texture read; the backward owns the
+    fragment read (20 B), the RGBA cotangent, faces read + gradient write and the texture-gradient write."""
+    if "backward" in call:
+        return 20 * H * W * K + 16 * H * W + 72 * F + 12 * Ht * Wt
+    return 24 * H * W * K + 16 * H * W + 36 * F + 12 * Ht * Wt
 
 
 def cpu_baseline(cfg, seconds_budget=25.0):
@@ -144,8 +148,8 @@ def main():
         per_call = native.timing_summary()
         native.enable_timing(False)
         dom = max(per_call, key=lambda k: per_call[k][1])
-        raster_ms = per_call["ur_rasterize_meshes"][1]
-        alg = B * raster_bytes_per_image(H, H, K, F)
+        raster_ms = per_call[dom][1]
+        alg = B * kernel_bytes_per_image(dom, H, H, K, F, cfg["tex"], cfg["tex"])
         achieved = alg / (raster_ms * 1e-3) / 1e9
         ips = world * B * a.steps / elapsed
         path_gbps = ips / world * path_bytes_per_image(H, H, K, F, cfg["tex"], cfg["tex"]) / 1e9
@@ -157,10 +161,13 @@ def main():
             "config": {"workload": a.workload, "batch_per_gpu": B, "image": [H, H], "faces_per_pixel": K,
                        "faces_per_mesh": F, "texture": [cfg["tex"], cfg["tex"]], "sigma": 1e-4,
                        "grads": "verts+texture+R+T"},
-            "roofline": {"bound": "hbm", "kernel": "k_raster (ur_rasterize_meshes)", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": {"ur_render_layered_forward": "k_raster<4,2>", "ur_render_layered_backward": "k_render_bwd"}.get(dom, dom), "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None, "algorithmic_bytes_per_launch": alg,
-                         "kernel_ms": round(raster_ms, 4), "dominant_call": dom},
+                         "kernel_ms": round(raster_ms, 4), "dominant_call": dom,
+                         "note": "algorithmic bytes = this launch's share of SURVEY 8(d) (fragments counted as if "
+                                 "materialised); the fused kernels keep fragments on chip, so real HBM traffic is "
+                                 "far below it -- see traffic / DESIGN.md"},
             "path_hbm": {"bytes_per_image": path_bytes_per_image(H, H, K, F, cfg["tex"], cfg["tex"]),
                          "achieved_GBps_per_gpu": round(path_gbps, 2),
                          "frac_of_peak": round(path_gbps / HBM_PEAK_GBPS, 4)},

@@ -68,7 +68,7 @@ int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t 
  *           perspective_correct, clip_barycentric_coords, cull_backfaces), call site renderer.py:46-49,54-57.
  * There is no bin_size / max_faces_per_bin: binning is internal (16x16 bins -> 8x8 tiles, lists in LDS, processed
  * in rounds) and cannot overflow.  perspective_correct must be 0 (the reference never enables it, renderer.py:47,55).
- *   face_verts (NF,3,3) ; mesh_first_face, mesh_num_faces (N) int64 (host or device? DEVICE) ;
+ *   face_verts (NF,3,3) ; mesh_first_face, mesh_num_faces (N) int64 ;
  *   outputs (N,H,W,K): pix_to_face int32, zbuf, dists fp32 ; bary (N,H,W,K,3).  Any of zbuf/bary/dists may be NULL.
  */
 int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
@@ -115,6 +115,35 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
                             const int64_t* mesh_first_face, int N, int H, int W, int K, int Ht, int Wt, float sigma,
                             const float* background, const float* ambient, int mode, float* grad_maps,
                             float* grad_bary, float* grad_dists, void* stream);
+
+/*
+ * Fused training path: rasterize + UV-sample + layered blend in ONE launch, and its backward in ONE launch.
+ * Replaces: MeshRenderer.forward = MeshRasterizer (renderer.py:48) + LayeredShader.forward (renderer.py:159-172) and
+ *           the autograd of both (trainer.py:151).  Numerically identical to ur_rasterize_meshes + ur_shade_blend:
+ * the blend stops at the first layer that hides everything behind it (alpha == 1 with zero d(alpha)/d(dist)), which
+ * changes neither the image nor any gradient.  No (N,H,W,K) fragment tensors are materialised: the forward leaves
+ * only `layers`, int32 [N][ceil(H/8)][ceil(W/8)][K][64] (ur_layers_elems() elements): per 8x8 tile, per depth slot,
+ * per pixel, the packed face index of the layers that matter, front to back, ended by -1.
+ *   workspace: ur_workspace_bytes(total_faces) bytes; the backward must be given the SAME buffer, untouched.
+ *   grad_face_verts (NF,3,3) and grad_maps (N,Ht,Wt,3) must be zero-filled by the caller; either may be NULL
+ *   (then that gradient is skipped).  The z column of grad_face_verts stays 0 (the layered blend never reads zbuf).
+ */
+size_t ur_layers_elems(int N, int H, int W, int K);
+
+int ur_render_layered_forward(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces,
+                              int N, int64_t total_faces, int H, int W, float blur_radius, int K,
+                              int clip_barycentric_coords, int cull_backfaces, const float* maps,
+                              const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                              const float* background, const float* ambient, int mode, float* image, int32_t* layers,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_first_face,
+                               const int64_t* mesh_num_faces, int N, int64_t total_faces, int H, int W,
+                               float blur_radius, int K, int clip_barycentric_coords, const float* maps,
+                               const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                               const float* background, const float* ambient, int mode, const int32_t* layers,
+                               const void* workspace, size_t workspace_bytes, float* grad_face_verts,
+                               float* grad_maps, void* stream);
 
 #ifdef __cplusplus
 }

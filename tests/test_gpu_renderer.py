@@ -10,13 +10,14 @@ from unicorn_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _setup(N, level, img, K, seed=0, sigma=1e-4, tex=64, cam=None, expand=True, **rkw):
+def _setup(N, level, img, K, seed=0, sigma=1e-4, tex=64, cam=None, expand=True, fused=True, **rkw):
     from unicorn_amd.renderer import Renderer
     from unicorn_amd.structures import Meshes, TexturesUV
     dev = torch.device("cuda:0")
     sc = synth.make_scene(N, level=level, tex_size=tex, seed=seed)
     cam = cam or {"name": "fov", "fov": 30}
     rend = Renderer(img, cameras=cam, faces_per_pixel=K, sigma=sigma, **rkw).to(dev)
+    rend.renderer.fused = rend.viz_renderer.fused = fused
     verts = sc["verts"].to(dev).requires_grad_(True)
     maps = sc["maps"].to(dev).requires_grad_(True)
     R = sc["R"].to(dev).requires_grad_(True)
@@ -53,9 +54,10 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "two-stage"])
 @pytest.mark.parametrize("N,level,img,K,cam", CASES)
-def test_forward_backward_match_oracle(N, level, img, K, cam):
-    sc, rend, meshes, (verts, maps, R, T) = _setup(N, level, img, K, seed=K + level, cam=cam)
+def test_forward_backward_match_oracle(N, level, img, K, cam, fused):
+    sc, rend, meshes, (verts, maps, R, T) = _setup(N, level, img, K, seed=K + level, cam=cam, fused=fused)
     H, W = (img, img) if isinstance(img, int) else img
     out = rend(meshes, R, T)
     assert out.shape == (N, 4, H, W) and out.dtype == torch.float32
@@ -71,8 +73,9 @@ def test_forward_backward_match_oracle(N, level, img, K, cam):
     assert rel_err(R.grad.cpu().numpy(), gR) <= 1e-4
 
 
-def test_sigmoid_blend_and_background():
-    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, 32, 12, seed=3, sigma=1e-3, clip_inside=False,
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "two-stage"])
+def test_sigmoid_blend_and_background(fused):
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, 32, 12, seed=3, sigma=1e-3, clip_inside=False, fused=fused,
                                                    background_color=(0.1, 0.6, 0.3))
     out = rend(meshes, R, T)
     cot = np.random.RandomState(1).randn(*out.shape).astype(np.float32)
@@ -175,3 +178,58 @@ def test_init_kwargs_roundtrip_and_unsupported():
     assert Renderer(64, **r.init_kwargs).renderer.rasterizer.raster_settings.faces_per_pixel == 50
     with pytest.raises(NotImplementedError):
         Renderer(64, layered_shader=False)
+
+
+def test_fused_equals_two_stage_bitwise_forward():
+    a = _setup(3, 3, 64, 50, seed=21, fused=True)
+    b = _setup(3, 3, 64, 50, seed=21, fused=False)
+    assert torch.equal(a[1](a[2], a[3][2], a[3][3]), b[1](b[2], b[3][2], b[3][3]))
+
+
+@pytest.mark.parametrize("mode_kw", [dict(clip_inside=False), dict(clip_inside=True)], ids=["sigmoid", "clip"])
+def test_deep_translucent_stacks(mode_kw):
+    """wide soft edges: many translucent layers per pixel (more than the backward keeps in LDS at once)"""
+    sigma, K, H = 3e-2, 30, 24
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, H, K, seed=13, sigma=sigma, **mode_kw)
+    out = rend(meshes, R, T)
+    cot = np.random.RandomState(5).randn(*out.shape).astype(np.float32)
+    (out * torch.from_numpy(cot).cuda()).sum().backward()
+    ref, (gv, gR, gT, gm) = _oracle(sc, H, H, K, S30, sigma, cot, **mode_kw)
+    frag = rend.renderer.rasterizer(meshes, R=R, T=T)
+    assert ((frag.pix_to_face >= 0).sum(-1) > 16).float().mean() > 0.3  # the stacks really are deep
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=0)
+    assert rel_err(maps.grad.cpu().numpy(), gm) <= 1e-4
+    assert rel_err(verts.grad.cpu().numpy(), gv) <= 1e-4
+    assert rel_err(T.grad.cpu().numpy(), gT) <= 1e-4
+
+
+def test_pixel_centres_exactly_on_edges():
+    """axis-aligned quad whose edges run through pixel centres: dist == 0 with alpha == 1 but d(alpha)/d(dist) != 0,
+    the one case where the layers BEHIND an opaque layer matter to the gradient"""
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesUV
+    dev = torch.device("cuda:0")
+    H = 8
+    s = 1.0
+    # two stacked quads (4 faces) at depth 2 and 3, in NDC-friendly world coords: camera = identity, focal 1
+    def quad(z, e):
+        return [[-e * z, -e * z, z], [e * z, -e * z, z], [e * z, e * z, z], [-e * z, e * z, z]]
+    verts = torch.tensor([quad(2.0, 0.375) + quad(3.0, 0.625)], dtype=torch.float32)  # edges at +-0.375, +-0.625
+    faces = torch.tensor([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]])
+    uvs = torch.rand(8, 2, generator=torch.Generator().manual_seed(0))
+    maps = torch.rand(1, 8, 8, 3, generator=torch.Generator().manual_seed(1))
+    R, T = torch.eye(3)[None], torch.zeros(1, 3)
+    rend = Renderer(H, cameras={"name": "perspective", "focal_length": s}, faces_per_pixel=6, sigma=1e-4).to(dev)
+    v, m = verts.to(dev).requires_grad_(True), maps.to(dev).requires_grad_(True)
+    meshes = Meshes(v, faces[None].to(dev), TexturesUV(m, faces[None].to(dev), uvs[None].to(dev)))
+    out = rend(meshes, R.to(dev), T.to(dev))
+    cot = np.random.RandomState(2).randn(1, 4, H, H).astype(np.float32)
+    (out * torch.from_numpy(cot).cuda()).sum().backward()
+    ref, (gv, gR, gT, gm) = orc.render_fwd_bwd(verts.numpy(), faces.numpy(), R.numpy(), T.numpy(), maps.numpy(),
+                                               uvs[None].numpy(), H, H, 6, s, grad_image=cot)
+    fv = orc.project_verts(verts.numpy(), R.numpy(), T.numpy(), s)[0][faces.numpy()]
+    ds = orc.rasterize(fv, 1, H, H, orc.blur_radius_for(1e-4), 6)[3]
+    assert (ds == 0).sum() > 0  # the case is really exercised
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=0)
+    assert rel_err(v.grad.cpu().numpy(), gv) <= 1e-4
+    assert rel_err(m.grad.cpu().numpy(), gm) <= 1e-4

@@ -87,7 +87,29 @@ struct RasterParams {
   int32_t* tl_counts;
   int32_t* tl_lists;
   int tl_cap;
+  // fused shading (MODE 2) and the fused backward
+  const float* maps;
+  const float* fuv;
+  int fuv_shared;
+  int Ht, Wt;
+  float sigma;
+  float bg[3];
+  float amb[3];
+  int use_amb;
+  int mode;
+  float* image;     // (N,4,H,W)
+  int32_t* layers;  // [N][TH][TW][K][64]: per tile, per depth slot, per lane (= pixel): the faces that matter for
+                    // the blend, front to back, ended by -1 (unless all K slots are used)
+  const float* gimage;
+  float* gmaps;
+  float* gfv;
 };
+
+// face-UV table row of packed face `fid` of mesh n
+__device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n, int fid) {
+  const int64_t fl = P.fuv_shared ? (int64_t)fid - P.first[n] : (int64_t)fid;
+  return P.fuv + fl * 6;
+}
 
 constexpr int kBinCap = 1024;  // bin-list entries held in LDS per round
 
@@ -107,7 +129,7 @@ __device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float
   return !(xc_hi < bb.x || xc_lo > bb.y || yc_hi < bb.z || yc_lo > bb.w);
 }
 
-// MODE 0: write fragments ; MODE 1: export tile lists
+// MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
 template <int WPB, int MODE>
 __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -242,6 +264,61 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
     return;
   }
   if (!tile_live) return;
+
+  if (MODE == 2) {
+    // ---- fused shading: walk this pixel's hits front to back, blend, stop at the first layer that hides the rest
+    const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+    int32_t* lay = P.layers + tile_id * (int64_t)K * 64 + lane;
+    float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+    unsigned long long last_key = 0;
+    bool first_take = true;
+    bool done = !pix_live;
+    int depth = 0;
+    while (true) {
+      const bool act = !done && depth < cnt;
+      if (!__any(act)) break;
+      if (act) {
+        unsigned long long best = ~0ull;
+        for (int i = 0; i < cnt; ++i) {
+          const unsigned long long kk = keys[(size_t)i * 64 + lane];
+          if ((first_take || kk > last_key) && kk < best) best = kk;
+        }
+        last_key = best;
+        first_take = false;
+        const int fid = (int)(unsigned)(best & 0xffffffffull);
+        const Face fc = load_face(P.rec, fid);
+        Eval ev;
+        eval_face(fc, px, py, P.blur, P.clip != 0, ev);
+        const float a = layer_alpha(ev.sd, true, P.sigma, P.mode);
+        const float* fu = face_uv_row(P, n, fid);
+        const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
+        const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
+        const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+        float cr, cg, cb;
+        sample_rgb(map, bl, P.Ht, P.Wt, cr, cg, cb);
+        if (P.use_amb) { cr *= P.amb[0]; cg *= P.amb[1]; cb *= P.amb[2]; }
+        r += occ * a * cr; g += occ * a * cg; b += occ * a * cb;
+        occ = occ * (1.0f - a);
+        lay[(int64_t)depth * 64] = fid;
+        ++depth;
+        // everything behind contributes exactly 0 to the image, and to the gradients as long as d(alpha)/d(dist)
+        // of this layer is 0 too (otherwise the backward needs what lies behind it)
+        done = (occ == 0.0f) && (layer_dalpha(ev.sd, a, true, P.sigma, P.mode) == 0.0f);
+      }
+    }
+    if (pix_live) {
+      if (depth < K) lay[(int64_t)depth * 64] = -1;
+      const int64_t hw = (int64_t)H * W;
+      float* img = P.image + (int64_t)n * 4 * hw + (int64_t)y * W + x;
+      img[0] = r + occ * 1.0f * P.bg[0];
+      img[hw] = g + occ * 1.0f * P.bg[1];
+      img[2 * hw] = b + occ * 1.0f * P.bg[2];
+      img[3 * hw] = 1.0f - occ;
+    } else {
+      lay[0] = -1;
+    }
+    return;
+  }
 
   // ---- output: ascending extraction, winners re-evaluated ----------------------------------------------------
   const int64_t ebase = (((int64_t)n * H + y) * W + x) * K;
@@ -433,6 +510,196 @@ __global__ void __launch_bounds__(256) k_raster_bwd(const float* __restrict__ fv
     for (int i = 0; i < 9; ++i)
       if (g[i] != 0.0f) atomicAdd(gfv + (int64_t)fid * 9 + i, g[i]);
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// fused backward of the layered render: grad_image -> grad_face_verts (xy only: the layered blend never reads zbuf),
+// grad_maps.  One wave per 8x8 tile, lane = pixel, walking the `layers` lists the forward left behind.
+//
+// With occ_k = prod_{j<k}(1-a_j), behind_k = colour composited from the layers behind k (dotted with the RGB
+// cotangent g) and trans_k = prod_{j>k}(1-a_j):
+//     dL/dcolour_k = occ_k a_k g                        -> texture scatter + uv -> barycentric -> vertex xy
+//     dL/da_k      = occ_k (c_k.g - behind_k) + g_A occ_k trans_k          -> signed distance -> vertex xy
+// The first line needs the layers in FRONT of k only, so it is finished during a front-to-back sweep; the second
+// needs the layers BEHIND k, so the sweep parks (occ, a, c.g, dist, d(dist)/d(edge ends)) in LDS and a back-to-front
+// sweep finishes it.  LDS holds kBwdD layers per lane; deeper lists are handled kBwdD layers at a time, back to
+// front, re-running the cheap part of the front sweep (rare: the forward stops a list at the first opaque layer).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kBwdD = 8;
+constexpr int kBwdWords = 10;  // occ, a, cg, sd, jax, jay, jbx, jby, fid, edge
+
+__device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, float px, float py, bool clip, float g0,
+                                              float g1, float g2, float o[6]) {
+  const float w0 = ev.w0, w1 = ev.w1, w2 = ev.w2;
+  float gw0 = g0, gw1 = g1, gw2 = g2;
+  if (clip) {
+    const float c0 = max_s(w0, 0.0f), c1 = max_s(w1, 0.0f), c2 = max_s(w2, 0.0f);
+    const float sraw = c0 + c1 + c2;
+    const float s = max_s(sraw, 1e-5f);
+    const float gs = (sraw < 1e-5f) ? 0.0f : -(g0 * c0 + g1 * c1 + g2 * c2) / (s * s);
+    gw0 = (w0 > 0.0f) ? (g0 / s + gs) : 0.0f;
+    gw1 = (w1 > 0.0f) ? (g1 / s + gs) : 0.0f;
+    gw2 = (w2 > 0.0f) ? (g2 / s + gs) : 0.0f;
+  }
+  const float ge0 = gw0 / f.denom, ge1 = gw1 / f.denom, ge2 = gw2 / f.denom;
+  const float gden = -(gw0 * w0 + gw1 * w1 + gw2 * w2) / f.denom;
+  float a0x = 0, a0y = 0, a1x = 0, a1y = 0, a2x = 0, a2y = 0;
+  edge_bwd(px, py, f.v1x, f.v1y, f.v2x, f.v2y, ge0, a1x, a1y, a2x, a2y);
+  edge_bwd(px, py, f.v2x, f.v2y, f.v0x, f.v0y, ge1, a2x, a2y, a0x, a0y);
+  edge_bwd(px, py, f.v0x, f.v0y, f.v1x, f.v1y, ge2, a0x, a0y, a1x, a1y);
+  edge_bwd(f.v2x, f.v2y, f.v0x, f.v0y, f.v1x, f.v1y, gden, a0x, a0y, a1x, a1y);
+  a2x += gden * (f.v1y - f.v0y);
+  a2y += -gden * (f.v1x - f.v0x);
+  o[0] = a0x; o[1] = a0y; o[2] = a1x; o[3] = a1y; o[4] = a2x; o[5] = a2y;
+}
+
+__global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sl = reinterpret_cast<float*>(smem) + (size_t)wave * kBwdWords * kBwdD * 64 + lane;
+#define SL(word, slot) sl[((word) * kBwdD + (slot)) * 64]
+  const int H = P.H, W = P.W, K = P.K;
+  const int TH = (H + 7) / 8, TW = (W + 7) / 8;
+  const int64_t ntiles = (int64_t)P.N * TH * TW;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int n = (int)(tile / (TH * TW));
+  const int t = (int)(tile - (int64_t)n * TH * TW);
+  const int ty = t / TW, tx = t - ty * TW;
+  const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+  const bool live = (x < W) && (y < H);
+  const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
+  const int32_t* lay = P.layers + tile * (int64_t)K * 64 + lane;
+
+  int depth = 0;
+  {
+    bool alive = live;
+    for (int k = 0; k < K; ++k) {
+      if (alive) alive = lay[(int64_t)k * 64] >= 0;
+      if (!__any(alive)) break;
+      depth += alive ? 1 : 0;
+    }
+  }
+  const int maxdepth = __builtin_amdgcn_readfirstlane(wave_max(depth));
+  if (maxdepth == 0) return;
+
+  const int64_t hw = (int64_t)H * W;
+  float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+  if (live) {
+    const float* gi = P.gimage + (int64_t)n * 4 * hw + (int64_t)y * W + x;
+    g0 = gi[0]; g1 = gi[hw]; g2 = gi[2 * hw]; g3 = gi[3 * hw];
+  }
+  const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+  float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
+  const bool clip = P.clip != 0;
+
+  float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+  float trans = 1.0f;
+  const int nchunks = (maxdepth + kBwdD - 1) / kBwdD;
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int k0 = c * kBwdD, k1 = min(maxdepth, k0 + kBwdD);
+    float occ = 1.0f;
+    for (int k = 0; k < k1; ++k) {
+      if (k >= depth) continue;
+      const int fid = lay[(int64_t)k * 64];
+      const Face fc = load_face(P.rec, fid);
+      Eval ev;
+      eval_face(fc, px, py, P.blur, clip, ev);
+      const float a = layer_alpha(ev.sd, true, P.sigma, P.mode);
+      if (k >= k0) {
+        const float* fu = face_uv_row(P, n, fid);
+        const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
+        const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
+        const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+        int onw, one, osw, ose;
+        bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
+        float tex[4][3], col[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          tex[0][ch] = map[onw + ch];
+          tex[1][ch] = one >= 0 ? map[one + ch] : 0.0f;
+          tex[2][ch] = osw >= 0 ? map[osw + ch] : 0.0f;
+          tex[3][ch] = ose >= 0 ? map[ose + ch] : 0.0f;
+          float acc = 0.0f;
+          acc += tex[0][ch] * bl.wnw; acc += tex[1][ch] * bl.wne; acc += tex[2][ch] * bl.wsw; acc += tex[3][ch] * bl.wse;
+          col[ch] = P.use_amb ? acc * P.amb[ch] : acc;
+        }
+        const float cg = g0 * col[0] + g1 * col[1] + g2 * col[2];
+        const float wgt = occ * a;
+        float jax = 0, jay = 0, jbx = 0, jby = 0;
+        int edge = 0;
+        if (wgt != 0.0f) {
+          float gc[3] = {wgt * g0, wgt * g1, wgt * g2};
+          if (P.use_amb) { gc[0] *= P.amb[0]; gc[1] *= P.amb[1]; gc[2] *= P.amb[2]; }
+          float gix = 0.0f, giy = 0.0f;
+          const float y1 = (float)(bl.y0 + 1), x1 = (float)(bl.x0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float g = gc[ch];
+            if (gmap) {
+              atomicAdd(gmap + onw + ch, g * bl.wnw);
+              if (one >= 0) atomicAdd(gmap + one + ch, g * bl.wne);
+              if (osw >= 0) atomicAdd(gmap + osw + ch, g * bl.wsw);
+              if (ose >= 0) atomicAdd(gmap + ose + ch, g * bl.wse);
+            }
+            gix -= tex[0][ch] * (y1 - bl.iy) * g; giy -= tex[0][ch] * (x1 - bl.ix) * g;
+            gix += tex[1][ch] * (y1 - bl.iy) * g; giy -= tex[1][ch] * (bl.ix - x0) * g;
+            gix -= tex[2][ch] * (bl.iy - y0) * g; giy += tex[2][ch] * (x1 - bl.ix) * g;
+            gix += tex[3][ch] * (bl.iy - y0) * g; giy += tex[3][ch] * (bl.ix - x0) * g;
+          }
+          if (P.gfv) {
+            const float gu = gix * bl.mx * 2.0f, gv = giy * bl.my * 2.0f;
+            const float gb0 = gu * fu[0] + gv * fu[1], gb1 = gu * fu[2] + gv * fu[3], gb2 = gu * fu[4] + gv * fu[5];
+            float o[6];
+            bary_path_bwd(fc, ev, px, py, clip, gb0, gb1, gb2, o);
+            float* gf = P.gfv + (int64_t)fid * 9;
+            if (o[0] != 0.0f) atomicAdd(gf + 0, o[0]);
+            if (o[1] != 0.0f) atomicAdd(gf + 1, o[1]);
+            if (o[2] != 0.0f) atomicAdd(gf + 3, o[2]);
+            if (o[3] != 0.0f) atomicAdd(gf + 4, o[3]);
+            if (o[4] != 0.0f) atomicAdd(gf + 6, o[4]);
+            if (o[5] != 0.0f) atomicAdd(gf + 7, o[5]);
+          }
+        }
+        if (P.gfv) {
+          // d(signed dist)/d(ends of the nearest edge); first minimal edge wins ties
+          const float sgn = ev.inside ? -1.0f : 1.0f;
+          if (ev.d01 <= ev.d02 && ev.d01 <= ev.d12) {
+            edge = 0; seg_bwd(px, py, fc.v0x, fc.v0y, fc.v1x, fc.v1y, sgn, jax, jay, jbx, jby);
+          } else if (ev.d02 <= ev.d01 && ev.d02 <= ev.d12) {
+            edge = 1; seg_bwd(px, py, fc.v0x, fc.v0y, fc.v2x, fc.v2y, sgn, jax, jay, jbx, jby);
+          } else {
+            edge = 2; seg_bwd(px, py, fc.v1x, fc.v1y, fc.v2x, fc.v2y, sgn, jax, jay, jbx, jby);
+          }
+        }
+        const int slot = k - k0;
+        SL(0, slot) = occ; SL(1, slot) = a; SL(2, slot) = cg; SL(3, slot) = ev.sd;
+        SL(4, slot) = jax; SL(5, slot) = jay; SL(6, slot) = jbx; SL(7, slot) = jby;
+        SL(8, slot) = __int_as_float(fid); SL(9, slot) = __int_as_float(edge);
+      }
+      occ = occ * (1.0f - a);
+    }
+    for (int k = k1 - 1; k >= k0; --k) {
+      if (k >= depth) continue;
+      const int slot = k - k0;
+      const float ok = SL(0, slot), a = SL(1, slot), cg = SL(2, slot), sd = SL(3, slot);
+      const float ga = ok * (cg - behind) + g3 * ok * trans;
+      const float gd = ga * layer_dalpha(sd, a, true, P.sigma, P.mode);
+      if (P.gfv && gd != 0.0f) {
+        const int fid = __float_as_int(SL(8, slot)), edge = __float_as_int(SL(9, slot));
+        const int va = (edge == 2) ? 1 : 0, vb = (edge == 0) ? 1 : 2;
+        float* gf = P.gfv + (int64_t)fid * 9;
+        atomicAdd(gf + va * 3 + 0, gd * SL(4, slot));
+        atomicAdd(gf + va * 3 + 1, gd * SL(5, slot));
+        atomicAdd(gf + vb * 3 + 0, gd * SL(6, slot));
+        atomicAdd(gf + vb * 3 + 1, gd * SL(7, slot));
+      }
+      behind = a * cg + (1.0f - a) * behind;
+      trans = trans * (1.0f - a);
+    }
+  }
+#undef SL
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -816,6 +1083,83 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
   if (lds > 64 * 1024) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d too large for the blend backward", K);
   hipLaunchKernelGGL(k_shade_bwd, dim3((unsigned)((npix + 63) / 64)), dim3(64), lds, (hipStream_t)stream, P);
   return check_launch("k_shade_bwd");
+}
+
+size_t ur_layers_elems(int N, int H, int W, int K) {
+  return (size_t)(N < 0 ? 0 : N) * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)K * 64;
+}
+
+static int fill_render_params(RasterParams& P, const int64_t* first, const int64_t* nfaces, int N, int H, int W,
+                              float blur, int K, int clip, const float* maps, const float* fuv, int fuv_shared, int Ht,
+                              int Wt, float sigma, const float* bg, const float* amb, int mode) {
+  if (!first || !nfaces || !maps || !fuv || !bg) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || Ht <= 0 || Wt <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (!(blur >= 0.0f)) return fail(UR_ERR_INVALID_ARG, "blur_radius must be >= 0");
+  if (mode < 0 || mode > 2) return fail(UR_ERR_INVALID_ARG, "bad blend mode %d", mode);
+  if (mode != UR_BLEND_HARD && !(sigma > 0.0f)) return fail(UR_ERR_INVALID_ARG, "sigma must be > 0 for soft blending");
+  P.first = first; P.nfaces = nfaces; P.N = N; P.H = H; P.W = W; P.K = K; P.blur = blur; P.clip = clip;
+  P.maps = maps; P.fuv = fuv; P.fuv_shared = fuv_shared; P.Ht = Ht; P.Wt = Wt; P.sigma = sigma; P.mode = mode;
+  for (int i = 0; i < 3; ++i) { P.bg[i] = bg[i]; P.amb[i] = amb ? amb[i] : 1.0f; }
+  P.use_amb = amb && !(amb[0] == 1.0f && amb[1] == 1.0f && amb[2] == 1.0f);
+  return UR_OK;
+}
+
+int ur_render_layered_forward(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces,
+                              int N, int64_t total_faces, int H, int W, float blur_radius, int K,
+                              int clip_barycentric_coords, int cull_backfaces, const float* maps,
+                              const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                              const float* background, const float* ambient, int mode, float* image, int32_t* layers,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (!face_verts || !image || !layers) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
+  RasterParams P{};
+  int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
+                              face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  const int wpb = pick_wpb(K);
+  if (!wpb) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d does not fit the 160 KB LDS (max %d)", K,
+                        (int)((160 * 1024 - kBinCap * 4 - 64) / 512));
+  if (N == 0) return UR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float4 *bbox, *rec;
+  rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, workspace, workspace_bytes, st, &bbox, &rec);
+  if (rc) return rc;
+  P.bbox = bbox; P.rec = rec; P.image = image; P.layers = layers;
+  if (wpb == 4) return launch_raster<4, 2>(P, st);
+  if (wpb == 2) return launch_raster<2, 2>(P, st);
+  return launch_raster<1, 2>(P, st);
+}
+
+int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_first_face,
+                               const int64_t* mesh_num_faces, int N, int64_t total_faces, int H, int W,
+                               float blur_radius, int K, int clip_barycentric_coords, const float* maps,
+                               const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                               const float* background, const float* ambient, int mode, const int32_t* layers,
+                               const void* workspace, size_t workspace_bytes, float* grad_face_verts,
+                               float* grad_maps, void* stream) {
+  if (!grad_image || !layers || !workspace) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
+  if (workspace_bytes < ur_workspace_bytes(total_faces)) return fail(UR_ERR_WORKSPACE, "workspace too small");
+  RasterParams P{};
+  int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
+                              face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (N == 0 || (!grad_face_verts && !grad_maps)) return UR_OK;
+  P.bbox = reinterpret_cast<const float4*>(workspace);
+  P.rec = P.bbox + total_faces;
+  P.layers = const_cast<int32_t*>(layers);
+  P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
+  const int64_t ntiles = (int64_t)N * ((H + 7) / 8) * ((W + 7) / 8);
+  const size_t lds = (size_t)4 * kBwdWords * kBwdD * 64 * 4;
+  static thread_local bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_bwd),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), lds, (hipStream_t)stream, P);
+  return check_launch("k_render_bwd");
 }
 
 }  // extern "C"

@@ -29,6 +29,11 @@ _SIGNATURES = {
     "ur_rasterize_meshes_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "ur_tile_faces": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ur_shade_blend": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
+    "ur_layers_elems": (_sz, [_i, _i, _i, _i]),
+    "ur_render_layered_forward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
+                                       _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ur_render_layered_backward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
+                                        _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ur_shade_blend_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i,
                                      _vp, _vp, _vp, _vp]),
 }
@@ -256,3 +261,46 @@ def shade_blend_backward(grad_image, pix_to_face, bary, dists, maps, face_uvs, f
                                              int(mode), _ptr(gmaps, None, True), _ptr(gbary), _ptr(gdists),
                                              _stream(maps)), "ur_shade_blend_backward")
     return gmaps, gbary, gdists
+
+
+def render_layered_forward(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_radius, faces_per_pixel,
+                           clip_barycentric_coords, maps, face_uvs, face_uvs_shared, sigma, background, ambient, mode,
+                           cull_backfaces=False):
+    """-> image (N,4,H,W), layers (int32, opaque), workspace (uint8, opaque); the last two feed the backward"""
+    _ptr(face_verts, torch.float32)
+    H, W = image_size
+    N, K, NF = int(mesh_first_face.shape[0]), int(faces_per_pixel), int(face_verts.shape[0])
+    Ht, Wt = maps.shape[1:3]
+    dev = face_verts.device
+    image = torch.empty(N, 4, H, W, dtype=torch.float32, device=dev)
+    layers = torch.empty(int(lib().ur_layers_elems(N, H, W, K)), dtype=torch.int32, device=dev)
+    ws = _workspace(NF, dev)
+    with _on(face_verts), _timed("ur_render_layered_forward", face_verts):
+        _check(lib().ur_render_layered_forward(
+            _ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64), _ptr(mesh_num_faces, torch.int64), N,
+            NF, H, W, float(blur_radius), K, int(clip_barycentric_coords), int(cull_backfaces),
+            _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt, float(sigma),
+            ctypes.cast(_rgb(background), _vp), ctypes.cast(_rgb(ambient), _vp) if ambient is not None else None,
+            int(mode), _ptr(image), _ptr(layers), _ptr(ws), ws.numel(), _stream(face_verts)),
+            "ur_render_layered_forward")
+    return image, layers, ws
+
+
+def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_faces, image_size, blur_radius,
+                            faces_per_pixel, clip_barycentric_coords, maps, face_uvs, face_uvs_shared, sigma,
+                            background, ambient, mode, layers, workspace, need_face_verts=True, need_maps=True):
+    H, W = image_size
+    N, K = int(mesh_first_face.shape[0]), int(faces_per_pixel)
+    Ht, Wt = maps.shape[1:3]
+    dev = maps.device
+    gfv = torch.zeros(total_faces, 3, 3, dtype=torch.float32, device=dev) if need_face_verts else None
+    gmaps = torch.zeros_like(maps) if need_maps else None
+    with _on(maps), _timed("ur_render_layered_backward", maps):
+        _check(lib().ur_render_layered_backward(
+            _ptr(grad_image, torch.float32), _ptr(mesh_first_face, torch.int64), _ptr(mesh_num_faces, torch.int64), N,
+            int(total_faces), H, W, float(blur_radius), K, int(clip_barycentric_coords), _ptr(maps, torch.float32),
+            _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt, float(sigma),
+            ctypes.cast(_rgb(background), _vp), ctypes.cast(_rgb(ambient), _vp) if ambient is not None else None,
+            int(mode), _ptr(layers, torch.int32), _ptr(workspace), workspace.numel(), _ptr(gfv, None, True),
+            _ptr(gmaps, None, True), _stream(maps)), "ur_render_layered_backward")
+    return gfv, gmaps

@@ -72,6 +72,38 @@ class _ShadeBlend(Function):
                 None, None, None)
 
 
+class _RenderLayered(Function):
+    """ur_render_layered_forward / _backward: rasterize + sample + blend in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, face_verts, maps, first, nfaces, image_size, blur_radius, K, clip, face_uvs, shared, sigma,
+                background, ambient, mode):
+        face_verts, maps = face_verts.contiguous(), maps.contiguous()
+        image, layers, ws = native.render_layered_forward(face_verts, first, nfaces, image_size, blur_radius, K, clip,
+                                                          maps, face_uvs, shared, sigma, background, ambient, mode)
+        ctx.save_for_backward(maps, first, nfaces, face_uvs, layers, ws)
+        ctx.cfg = (image_size, blur_radius, K, clip, shared, sigma, background, ambient, mode, face_verts.shape[0])
+        return image
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_image):
+        maps, first, nfaces, face_uvs, layers, ws = ctx.saved_tensors
+        image_size, blur_radius, K, clip, shared, sigma, background, ambient, mode, NF = ctx.cfg
+        need_fv, need_maps = ctx.needs_input_grad[:2]
+        gfv, gmaps = native.render_layered_backward(grad_image.contiguous(), first, nfaces, NF, image_size,
+                                                    blur_radius, K, clip, maps, face_uvs, shared, sigma, background,
+                                                    ambient, mode, layers, ws, need_fv, need_maps)
+        return (gfv, gmaps) + (None,) * 12
+
+
+def render_layered(face_verts, maps, first, nfaces, image_size, blur_radius, K, clip, face_uvs, shared, sigma,
+                   background, ambient, mode):
+    return _RenderLayered.apply(face_verts, maps, first, nfaces, tuple(image_size), float(blur_radius), int(K),
+                                bool(clip), face_uvs, bool(shared), float(sigma), tuple(background),
+                                None if ambient is None else tuple(ambient), int(mode))
+
+
 def project_faces(verts, faces, R, T, sx, sy):
     return _ProjectFaces.apply(verts, faces, R, T, float(sx), float(sy))
 

@@ -163,6 +163,18 @@ class LayeredShader(nn.Module):
             return native.BLEND_HARD
         return native.BLEND_CLIP_INSIDE if self.clip_inside else native.BLEND_SIGMOID
 
+    def render_fused(self, rasterizer, meshes, R=None, T=None, **kwargs):
+        bp = kwargs.get("blend_params", self.blend_params)
+        rs = kwargs.get("raster_settings", rasterizer.raster_settings)
+        tex = meshes.textures
+        face_verts, first, nf = rasterizer.transform(meshes, R, T)
+        ambient = _rgb3(self.lights.ambient_color)
+        face_uvs, shared = tex.faces_verts_uvs()
+        return ops.render_layered(face_verts, tex.maps_padded().float(), first, nf, rs.image_size, rs.blur_radius,
+                                  rs.faces_per_pixel, rs.clip_barycentric_coords, face_uvs.float(), shared, bp.sigma,
+                                  _rgb3(bp.background_color), None if ambient == (1.0, 1.0, 1.0) else ambient,
+                                  self.blend_mode(bp))
+
     def forward(self, fragments, meshes, **kwargs):
         bp = kwargs.get("blend_params", self.blend_params)
         tex = meshes.textures
@@ -177,9 +189,13 @@ class LayeredShader(nn.Module):
 
 
 class MeshRenderer(nn.Module):
-    def __init__(self, rasterizer, shader):
+    """rasterizer + shader.  With a LayeredShader over UV textures (the training configuration) both stages and
+    their backward run as ONE fused kernel each way (ur_render_layered_*); `fused=False` forces the two-stage path
+    through materialised Fragments (same numbers, used by tests and by callers that want the fragments)."""
+
+    def __init__(self, rasterizer, shader, fused=True):
         super().__init__()
-        self.rasterizer, self.shader = rasterizer, shader
+        self.rasterizer, self.shader, self.fused = rasterizer, shader, fused
 
     def to(self, device):
         self.rasterizer.to(device)
@@ -187,6 +203,8 @@ class MeshRenderer(nn.Module):
         return self
 
     def forward(self, meshes, **kwargs):
+        if self.fused and isinstance(self.shader, LayeredShader) and isinstance(meshes.textures, TexturesUV):
+            return self.shader.render_fused(self.rasterizer, meshes, **kwargs)
         fragments = self.rasterizer(meshes, **kwargs)
         return self.shader(fragments, meshes, **kwargs)
 
