@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C4_B32_128x128_K50_ico3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grads", default="verts+texture+R+T", help="which inputs require grad (ablation only; the "
+                    "reported metric uses the default = all of them)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,10 +107,11 @@ def main():
     sc = synth.make_scene(B, level=cfg["level"], tex_size=cfg["tex"], seed=100 * rank, device=dev)
     F = sc["faces"].shape[0]
     rend = Renderer(H, cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=1e-4).to(dev)
-    verts = sc["verts"].requires_grad_(True)
-    maps = sc["maps"].requires_grad_(True)
-    R = sc["R"].requires_grad_(True)
-    T = sc["T"].requires_grad_(True)
+    want = set(a.grads.split("+"))
+    verts = sc["verts"].requires_grad_("verts" in want)
+    maps = sc["maps"].requires_grad_("texture" in want)
+    R = sc["R"].requires_grad_("R" in want)
+    T = sc["T"].requires_grad_("T" in want)
     fb, ub = sc["faces"][None].expand(B, -1, -1), sc["verts_uvs"][None].expand(B, -1, -1)
     cot = torch.randn(B, 4, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
 
@@ -160,7 +163,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": a.workload, "batch_per_gpu": B, "image": [H, H], "faces_per_pixel": K,
                        "faces_per_mesh": F, "texture": [cfg["tex"], cfg["tex"]], "sigma": 1e-4,
-                       "grads": "verts+texture+R+T"},
+                       "grads": a.grads},
             "roofline": {"bound": "hbm", "kernel": {"ur_render_layered_forward": "k_raster<4,2>", "ur_render_layered_backward": "k_render_bwd"}.get(dom, dom), "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None, "algorithmic_bytes_per_launch": alg,

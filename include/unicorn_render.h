@@ -122,8 +122,9 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
  *           the autograd of both (trainer.py:151).  Numerically identical to ur_rasterize_meshes + ur_shade_blend:
  * the blend stops at the first layer that hides everything behind it (alpha == 1 with zero d(alpha)/d(dist)), which
  * changes neither the image nor any gradient.  No (N,H,W,K) fragment tensors are materialised: the forward leaves
- * only `layers`, int32 [N][ceil(H/8)][ceil(W/8)][K][64] (ur_layers_elems() elements): per 8x8 tile, per depth slot,
- * per pixel, the packed face index of the layers that matter, front to back, ended by -1.
+ * only `layers`, ur_layers_elems() int32 words laid out [N][ceil(H/8)][ceil(W/8)][K][64][2]: per 8x8 tile, per depth
+ * slot, per pixel, (packed face index, bits of the transmittance in front of that layer) of the layers that matter,
+ * front to back, ended by face = -1.  Only the first few depth slots of a tile are ever touched.
  *   workspace: ur_workspace_bytes(total_faces) bytes; the backward must be given the SAME buffer, untouched.
  *   grad_face_verts (NF,3,3) and grad_maps (N,Ht,Wt,3) must be zero-filled by the caller; either may be NULL
  *   (then that gradient is skipped).  The z column of grad_face_verts stays 0 (the layered blend never reads zbuf).

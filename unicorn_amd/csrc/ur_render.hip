@@ -98,8 +98,9 @@ struct RasterParams {
   int use_amb;
   int mode;
   float* image;     // (N,4,H,W)
-  int32_t* layers;  // [N][TH][TW][K][64]: per tile, per depth slot, per lane (= pixel): the faces that matter for
-                    // the blend, front to back, ended by -1 (unless all K slots are used)
+  int32_t* layers;  // int2 [N][TH][TW][K][64]: per tile, per depth slot, per lane (= pixel): (face, bits of the
+                    // transmittance in front of it) of the layers that matter for the blend, front to back, ended
+                    // by face = -1 (unless all K slots are used)
   const float* gimage;
   float* gmaps;
   float* gfv;
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
   if (MODE == 2) {
     // ---- fused shading: walk this pixel's hits front to back, blend, stop at the first layer that hides the rest
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
-    int32_t* lay = P.layers + tile_id * (int64_t)K * 64 + lane;
+    int2* lay = reinterpret_cast<int2*>(P.layers) + tile_id * (int64_t)K * 64 + lane;
     float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
     unsigned long long last_key = 0;
     bool first_take = true;
@@ -297,9 +298,9 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
         float cr, cg, cb;
         sample_rgb(map, bl, P.Ht, P.Wt, cr, cg, cb);
         if (P.use_amb) { cr *= P.amb[0]; cg *= P.amb[1]; cb *= P.amb[2]; }
+        lay[(int64_t)depth * 64] = make_int2(fid, __float_as_int(occ));
         r += occ * a * cr; g += occ * a * cg; b += occ * a * cb;
         occ = occ * (1.0f - a);
-        lay[(int64_t)depth * 64] = fid;
         ++depth;
         // everything behind contributes exactly 0 to the image, and to the gradients as long as d(alpha)/d(dist)
         // of this layer is 0 too (otherwise the backward needs what lies behind it)
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
       }
     }
     if (pix_live) {
-      if (depth < K) lay[(int64_t)depth * 64] = -1;
+      if (depth < K) lay[(int64_t)depth * 64] = make_int2(-1, 0);
       const int64_t hw = (int64_t)H * W;
       float* img = P.image + (int64_t)n * 4 * hw + (int64_t)y * W + x;
       img[0] = r + occ * 1.0f * P.bg[0];
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
       img[2 * hw] = b + occ * 1.0f * P.bg[2];
       img[3 * hw] = 1.0f - occ;
     } else {
-      lay[0] = -1;
+      lay[0] = make_int2(-1, 0);
     }
     return;
   }
@@ -515,19 +516,21 @@ __global__ void __launch_bounds__(256) k_raster_bwd(const float* __restrict__ fv
 
 // ------------------------------------------------------------------------------------------------------------------
 // fused backward of the layered render: grad_image -> grad_face_verts (xy only: the layered blend never reads zbuf),
-// grad_maps.  One wave per 8x8 tile, lane = pixel, walking the `layers` lists the forward left behind.
+// grad_maps.  Same decomposition as the forward: workgroup = 16x16 bin, wave = 8x8 tile, lane = pixel.
 //
-// With occ_k = prod_{j<k}(1-a_j), behind_k = colour composited from the layers behind k (dotted with the RGB
-// cotangent g) and trans_k = prod_{j>k}(1-a_j):
-//     dL/dcolour_k = occ_k a_k g                        -> texture scatter + uv -> barycentric -> vertex xy
-//     dL/da_k      = occ_k (c_k.g - behind_k) + g_A occ_k trans_k          -> signed distance -> vertex xy
-// The first line needs the layers in FRONT of k only, so it is finished during a front-to-back sweep; the second
-// needs the layers BEHIND k, so the sweep parks (occ, a, c.g, dist, d(dist)/d(edge ends)) in LDS and a back-to-front
-// sweep finishes it.  LDS holds kBwdD layers per lane; deeper lists are handled kBwdD layers at a time, back to
-// front, re-running the cheap part of the front sweep (rare: the forward stops a list at the first opaque layer).
+// With occ_k = prod_{j<k}(1-a_j) (saved by the forward next to the face index), behind_k = colour composited from
+// the layers behind k, dotted with the RGB cotangent g, and trans_k = prod_{j>k}(1-a_j):
+//     dL/dcolour_k = occ_k a_k g                          -> texture scatter + uv -> barycentrics -> vertex xy
+//     dL/da_k      = occ_k (c_k.g - behind_k) + g_A occ_k trans_k            -> signed distance -> vertex xy
+// so ONE back-to-front sweep over the list has everything it needs; nothing is parked per layer.
+//
+// Scatter: instead of one global float atomic per (pixel, layer, component) -- 64 lanes hitting 64 different faces /
+// texture rows, the slowest shape for the memory-side atomic units -- the workgroup first sums in two small LDS
+// tables (ds_add_f32), keyed by face index / texel index, claimed with an LDS compare-and-swap on a tag; a key whose
+// slot is taken by another key falls back to the global atomic.  One flush per workgroup at the end.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kBwdD = 8;
-constexpr int kBwdWords = 10;  // occ, a, cg, sd, jax, jay, jbx, jby, fid, edge
+constexpr int kFaceSlots = 512;  // x 6 floats
+constexpr int kTexSlots = 256;   // x 3 floats ; slot = 16x16 torus over (texel row, texel column)
 
 __device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, float px, float py, bool clip, float g0,
                                               float g1, float g2, float o[6]) {
@@ -551,155 +554,175 @@ __device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, flo
   edge_bwd(f.v2x, f.v2y, f.v0x, f.v0y, f.v1x, f.v1y, gden, a0x, a0y, a1x, a1y);
   a2x += gden * (f.v1y - f.v0y);
   a2y += -gden * (f.v1x - f.v0x);
-  o[0] = a0x; o[1] = a0y; o[2] = a1x; o[3] = a1y; o[4] = a2x; o[5] = a2y;
+  o[0] += a0x; o[1] += a0y; o[2] += a1x; o[3] += a1y; o[4] += a2x; o[5] += a2y;
+}
+
+// claim-or-match a slot of an LDS table; true when `key` owns slot h
+__device__ __forceinline__ bool lds_claim(int* tags, int h, int key) {
+  const int old = atomicCAS(&tags[h], -1, key);
+  return old == -1 || old == key;
 }
 
 __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_ftag[kFaceSlots];
+  __shared__ float s_fval[kFaceSlots * 6];
+  __shared__ int s_ttag[kTexSlots];
+  __shared__ float s_tval[kTexSlots * 3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* sl = reinterpret_cast<float*>(smem) + (size_t)wave * kBwdWords * kBwdD * 64 + lane;
-#define SL(word, slot) sl[((word) * kBwdD + (slot)) * 64]
+  for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
+  for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0f;
+  for (int i = tid; i < kTexSlots; i += 256) s_ttag[i] = -1;
+  for (int i = tid; i < kTexSlots * 3; i += 256) s_tval[i] = 0.0f;
+  __syncthreads();
+
   const int H = P.H, W = P.W, K = P.K;
-  const int TH = (H + 7) / 8, TW = (W + 7) / 8;
-  const int64_t ntiles = (int64_t)P.N * TH * TW;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  if (tile >= ntiles) return;
-  const int n = (int)(tile / (TH * TW));
-  const int t = (int)(tile - (int64_t)n * TH * TW);
-  const int ty = t / TW, tx = t - ty * TW;
-  const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+  const int TW = (W + 7) / 8;
+  const int bins_per_img = P.nbx * P.nby;
+  const int n = blockIdx.x / bins_per_img;
+  const int b = blockIdx.x - n * bins_per_img;
+  const int by = b / P.nbx, bx = b - by * P.nbx;
+  const int tx0 = bx * 16 + (wave & 1) * 8, ty0 = by * 16 + (wave >> 1) * 8;
+  const bool tile_live = (tx0 < W) && (ty0 < H);
+  const int x = tx0 + (lane & 7), y = ty0 + (lane >> 3);
   const bool live = (x < W) && (y < H);
   const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
-  const int32_t* lay = P.layers + tile * (int64_t)K * 64 + lane;
+  const int64_t tile_id = ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * TW + (tx0 >> 3);
+  const int2* lay = reinterpret_cast<const int2*>(P.layers) + (tile_live ? tile_id : 0) * (int64_t)K * 64 + lane;
+  float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
 
   int depth = 0;
-  {
+  if (tile_live) {
     bool alive = live;
     for (int k = 0; k < K; ++k) {
-      if (alive) alive = lay[(int64_t)k * 64] >= 0;
+      if (alive) alive = lay[(int64_t)k * 64].x >= 0;
       if (!__any(alive)) break;
       depth += alive ? 1 : 0;
     }
   }
   const int maxdepth = __builtin_amdgcn_readfirstlane(wave_max(depth));
-  if (maxdepth == 0) return;
 
-  const int64_t hw = (int64_t)H * W;
-  float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-  if (live) {
-    const float* gi = P.gimage + (int64_t)n * 4 * hw + (int64_t)y * W + x;
-    g0 = gi[0]; g1 = gi[hw]; g2 = gi[2 * hw]; g3 = gi[3 * hw];
-  }
-  const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
-  float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
-  const bool clip = P.clip != 0;
-
-  float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
-  float trans = 1.0f;
-  const int nchunks = (maxdepth + kBwdD - 1) / kBwdD;
-  for (int c = nchunks - 1; c >= 0; --c) {
-    const int k0 = c * kBwdD, k1 = min(maxdepth, k0 + kBwdD);
-    float occ = 1.0f;
-    for (int k = 0; k < k1; ++k) {
+  if (maxdepth > 0) {
+    const int64_t hw = (int64_t)H * W;
+    float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+    if (live) {
+      const float* gi = P.gimage + (int64_t)n * 4 * hw + (int64_t)y * W + x;
+      g0 = gi[0]; g1 = gi[hw]; g2 = gi[2 * hw]; g3 = gi[3 * hw];
+    }
+    const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+    const bool clip = P.clip != 0;
+    float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+    float trans = 1.0f;
+    for (int k = maxdepth - 1; k >= 0; --k) {
       if (k >= depth) continue;
-      const int fid = lay[(int64_t)k * 64];
+      const int2 le = lay[(int64_t)k * 64];
+      const int fid = le.x;
+      const float occ = __int_as_float(le.y);
       const Face fc = load_face(P.rec, fid);
       Eval ev;
       eval_face(fc, px, py, P.blur, clip, ev);
       const float a = layer_alpha(ev.sd, true, P.sigma, P.mode);
-      if (k >= k0) {
-        const float* fu = face_uv_row(P, n, fid);
-        const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
-        const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
-        const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
-        int onw, one, osw, ose;
-        bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
-        float tex[4][3], col[3];
+      const float* fu = face_uv_row(P, n, fid);
+      const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
+      const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
+      const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+      int onw, one, osw, ose;
+      bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
+      float tex[4][3], col[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        tex[0][ch] = map[onw + ch];
+        tex[1][ch] = one >= 0 ? map[one + ch] : 0.0f;
+        tex[2][ch] = osw >= 0 ? map[osw + ch] : 0.0f;
+        tex[3][ch] = ose >= 0 ? map[ose + ch] : 0.0f;
+        float acc = 0.0f;
+        acc += tex[0][ch] * bl.wnw; acc += tex[1][ch] * bl.wne; acc += tex[2][ch] * bl.wsw; acc += tex[3][ch] * bl.wse;
+        col[ch] = P.use_amb ? acc * P.amb[ch] : acc;
+      }
+      const float cg = g0 * col[0] + g1 * col[1] + g2 * col[2];
+      const float ga = occ * (cg - behind) + g3 * occ * trans;
+      const float gd = ga * layer_dalpha(ev.sd, a, true, P.sigma, P.mode);
+      const float wgt = occ * a;
+      float o[6] = {0, 0, 0, 0, 0, 0};
+      if (wgt != 0.0f) {
+        float gc[3] = {wgt * g0, wgt * g1, wgt * g2};
+        if (P.use_amb) { gc[0] *= P.amb[0]; gc[1] *= P.amb[1]; gc[2] *= P.amb[2]; }
+        float gix = 0.0f, giy = 0.0f;
+        const float y1 = (float)(bl.y0 + 1), x1 = (float)(bl.x0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          tex[0][ch] = map[onw + ch];
-          tex[1][ch] = one >= 0 ? map[one + ch] : 0.0f;
-          tex[2][ch] = osw >= 0 ? map[osw + ch] : 0.0f;
-          tex[3][ch] = ose >= 0 ? map[ose + ch] : 0.0f;
-          float acc = 0.0f;
-          acc += tex[0][ch] * bl.wnw; acc += tex[1][ch] * bl.wne; acc += tex[2][ch] * bl.wsw; acc += tex[3][ch] * bl.wse;
-          col[ch] = P.use_amb ? acc * P.amb[ch] : acc;
+          const float g = gc[ch];
+          gix -= tex[0][ch] * (y1 - bl.iy) * g; giy -= tex[0][ch] * (x1 - bl.ix) * g;
+          gix += tex[1][ch] * (y1 - bl.iy) * g; giy -= tex[1][ch] * (bl.ix - x0) * g;
+          gix -= tex[2][ch] * (bl.iy - y0) * g; giy += tex[2][ch] * (x1 - bl.ix) * g;
+          gix += tex[3][ch] * (bl.iy - y0) * g; giy += tex[3][ch] * (bl.ix - x0) * g;
         }
-        const float cg = g0 * col[0] + g1 * col[1] + g2 * col[2];
-        const float wgt = occ * a;
-        float jax = 0, jay = 0, jbx = 0, jby = 0;
-        int edge = 0;
-        if (wgt != 0.0f) {
-          float gc[3] = {wgt * g0, wgt * g1, wgt * g2};
-          if (P.use_amb) { gc[0] *= P.amb[0]; gc[1] *= P.amb[1]; gc[2] *= P.amb[2]; }
-          float gix = 0.0f, giy = 0.0f;
-          const float y1 = (float)(bl.y0 + 1), x1 = (float)(bl.x0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
+        if (gmap) {
+          const int offs[4] = {onw, one, osw, ose};
+          const float wts[4] = {bl.wnw, bl.wne, bl.wsw, bl.wse};
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            const float g = gc[ch];
-            if (gmap) {
-              atomicAdd(gmap + onw + ch, g * bl.wnw);
-              if (one >= 0) atomicAdd(gmap + one + ch, g * bl.wne);
-              if (osw >= 0) atomicAdd(gmap + osw + ch, g * bl.wsw);
-              if (ose >= 0) atomicAdd(gmap + ose + ch, g * bl.wse);
+          for (int q = 0; q < 4; ++q) {
+            if (offs[q] < 0) continue;
+            const int texel = offs[q] / 3;
+            const int trow = texel / P.Wt, tcol = texel - trow * P.Wt;
+            const int h = ((trow & 15) << 4) | (tcol & 15);
+            if (lds_claim(s_ttag, h, texel)) {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) atomicAdd(&s_tval[h * 3 + ch], gc[ch] * wts[q]);
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) atomicAdd(gmap + offs[q] + ch, gc[ch] * wts[q]);
             }
-            gix -= tex[0][ch] * (y1 - bl.iy) * g; giy -= tex[0][ch] * (x1 - bl.ix) * g;
-            gix += tex[1][ch] * (y1 - bl.iy) * g; giy -= tex[1][ch] * (bl.ix - x0) * g;
-            gix -= tex[2][ch] * (bl.iy - y0) * g; giy += tex[2][ch] * (x1 - bl.ix) * g;
-            gix += tex[3][ch] * (bl.iy - y0) * g; giy += tex[3][ch] * (bl.ix - x0) * g;
-          }
-          if (P.gfv) {
-            const float gu = gix * bl.mx * 2.0f, gv = giy * bl.my * 2.0f;
-            const float gb0 = gu * fu[0] + gv * fu[1], gb1 = gu * fu[2] + gv * fu[3], gb2 = gu * fu[4] + gv * fu[5];
-            float o[6];
-            bary_path_bwd(fc, ev, px, py, clip, gb0, gb1, gb2, o);
-            float* gf = P.gfv + (int64_t)fid * 9;
-            if (o[0] != 0.0f) atomicAdd(gf + 0, o[0]);
-            if (o[1] != 0.0f) atomicAdd(gf + 1, o[1]);
-            if (o[2] != 0.0f) atomicAdd(gf + 3, o[2]);
-            if (o[3] != 0.0f) atomicAdd(gf + 4, o[3]);
-            if (o[4] != 0.0f) atomicAdd(gf + 6, o[4]);
-            if (o[5] != 0.0f) atomicAdd(gf + 7, o[5]);
           }
         }
         if (P.gfv) {
-          // d(signed dist)/d(ends of the nearest edge); first minimal edge wins ties
-          const float sgn = ev.inside ? -1.0f : 1.0f;
-          if (ev.d01 <= ev.d02 && ev.d01 <= ev.d12) {
-            edge = 0; seg_bwd(px, py, fc.v0x, fc.v0y, fc.v1x, fc.v1y, sgn, jax, jay, jbx, jby);
-          } else if (ev.d02 <= ev.d01 && ev.d02 <= ev.d12) {
-            edge = 1; seg_bwd(px, py, fc.v0x, fc.v0y, fc.v2x, fc.v2y, sgn, jax, jay, jbx, jby);
-          } else {
-            edge = 2; seg_bwd(px, py, fc.v1x, fc.v1y, fc.v2x, fc.v2y, sgn, jax, jay, jbx, jby);
-          }
+          const float gu = gix * bl.mx * 2.0f, gv = giy * bl.my * 2.0f;
+          const float gb0 = gu * fu[0] + gv * fu[1], gb1 = gu * fu[2] + gv * fu[3], gb2 = gu * fu[4] + gv * fu[5];
+          bary_path_bwd(fc, ev, px, py, clip, gb0, gb1, gb2, o);
         }
-        const int slot = k - k0;
-        SL(0, slot) = occ; SL(1, slot) = a; SL(2, slot) = cg; SL(3, slot) = ev.sd;
-        SL(4, slot) = jax; SL(5, slot) = jay; SL(6, slot) = jbx; SL(7, slot) = jby;
-        SL(8, slot) = __int_as_float(fid); SL(9, slot) = __int_as_float(edge);
       }
-      occ = occ * (1.0f - a);
-    }
-    for (int k = k1 - 1; k >= k0; --k) {
-      if (k >= depth) continue;
-      const int slot = k - k0;
-      const float ok = SL(0, slot), a = SL(1, slot), cg = SL(2, slot), sd = SL(3, slot);
-      const float ga = ok * (cg - behind) + g3 * ok * trans;
-      const float gd = ga * layer_dalpha(sd, a, true, P.sigma, P.mode);
       if (P.gfv && gd != 0.0f) {
-        const int fid = __float_as_int(SL(8, slot)), edge = __float_as_int(SL(9, slot));
-        const int va = (edge == 2) ? 1 : 0, vb = (edge == 0) ? 1 : 2;
-        float* gf = P.gfv + (int64_t)fid * 9;
-        atomicAdd(gf + va * 3 + 0, gd * SL(4, slot));
-        atomicAdd(gf + va * 3 + 1, gd * SL(5, slot));
-        atomicAdd(gf + vb * 3 + 0, gd * SL(6, slot));
-        atomicAdd(gf + vb * 3 + 1, gd * SL(7, slot));
+        // d(signed dist)/d(ends of the nearest edge); first minimal edge wins ties
+        const float gs = ev.inside ? -gd : gd;
+        if (ev.d01 <= ev.d02 && ev.d01 <= ev.d12)
+          seg_bwd(px, py, fc.v0x, fc.v0y, fc.v1x, fc.v1y, gs, o[0], o[1], o[2], o[3]);
+        else if (ev.d02 <= ev.d01 && ev.d02 <= ev.d12)
+          seg_bwd(px, py, fc.v0x, fc.v0y, fc.v2x, fc.v2y, gs, o[0], o[1], o[4], o[5]);
+        else
+          seg_bwd(px, py, fc.v1x, fc.v1y, fc.v2x, fc.v2y, gs, o[2], o[3], o[4], o[5]);
+      }
+      if (P.gfv && (wgt != 0.0f || gd != 0.0f)) {
+        const int h = fid & (kFaceSlots - 1);
+        if (lds_claim(s_ftag, h, fid)) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            if (o[i] != 0.0f) atomicAdd(&s_fval[h * 6 + i], o[i]);
+        } else {
+          float* gf = P.gfv + (int64_t)fid * 9;
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            if (o[i] != 0.0f) atomicAdd(gf + (i >> 1) * 3 + (i & 1), o[i]);
+        }
       }
       behind = a * cg + (1.0f - a) * behind;
       trans = trans * (1.0f - a);
     }
   }
-#undef SL
+
+  __syncthreads();
+  if (P.gfv)
+    for (int i = tid; i < kFaceSlots * 6; i += 256) {
+      const int slot = i / 6, c = i - slot * 6;
+      const int tag = s_ftag[slot];
+      const float v = s_fval[i];
+      if (tag >= 0 && v != 0.0f) atomicAdd(P.gfv + (int64_t)tag * 9 + (c >> 1) * 3 + (c & 1), v);
+    }
+  if (gmap)
+    for (int i = tid; i < kTexSlots * 3; i += 256) {
+      const int slot = i / 3, c = i - slot * 3;
+      const int tag = s_ttag[slot];
+      const float v = s_tval[i];
+      if (tag >= 0 && v != 0.0f) atomicAdd(gmap + (int64_t)tag * 3 + c, v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1086,7 +1109,7 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
 }
 
 size_t ur_layers_elems(int N, int H, int W, int K) {
-  return (size_t)(N < 0 ? 0 : N) * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)K * 64;
+  return (size_t)(N < 0 ? 0 : N) * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)K * 64 * 2;
 }
 
 static int fill_render_params(RasterParams& P, const int64_t* first, const int64_t* nfaces, int N, int H, int W,
@@ -1149,16 +1172,11 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   P.rec = P.bbox + total_faces;
   P.layers = const_cast<int32_t*>(layers);
   P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
-  const int64_t ntiles = (int64_t)N * ((H + 7) / 8) * ((W + 7) / 8);
-  const size_t lds = (size_t)4 * kBwdWords * kBwdD * 64 * 4;
-  static thread_local bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_bwd),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), lds, (hipStream_t)stream, P);
+  P.nbx = (W + 15) / 16;
+  P.nby = (H + 15) / 16;
+  const int64_t blocks = (int64_t)N * P.nbx * P.nby;
+  if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
+  hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
   return check_launch("k_render_bwd");
 }
 
