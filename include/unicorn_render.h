@@ -40,8 +40,9 @@ extern "C" {
 const char* ur_last_error(void);
 int ur_abi_version(void);
 
-/* Bytes of device workspace the raster / render entry points need for `total_faces` packed faces. */
-size_t ur_workspace_bytes(int64_t total_faces);
+/* Bytes of device workspace the raster / render entry points need: per-face records for `total_faces` packed faces
+ * plus, when faces_per_pixel K exceeds what the LDS holds per pixel, a spill area for the per-pixel top-K lists. */
+size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K);
 
 /*
  * World -> view -> NDC of every face corner, fused with the face gather.
@@ -67,7 +68,7 @@ int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t 
  *           clipped_faces_neighbor_idx, image_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin,
  *           perspective_correct, clip_barycentric_coords, cull_backfaces), call site renderer.py:46-49,54-57.
  * There is no bin_size / max_faces_per_bin: binning is internal (16x16 bins -> 8x8 tiles, lists in LDS, processed
- * in rounds) and cannot overflow.  perspective_correct must be 0 (the reference never enables it, renderer.py:47,55).
+ * in rounds) and cannot overflow; any faces_per_pixel is accepted.  perspective_correct must be 0 (the reference never enables it, renderer.py:47,55).
  *   face_verts (NF,3,3) ; mesh_first_face, mesh_num_faces (N) int64 ;
  *   outputs (N,H,W,K): pix_to_face int32, zbuf, dists fp32 ; bary (N,H,W,K,3).  Any of zbuf/bary/dists may be NULL.
  */
@@ -125,7 +126,7 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
  * only `layers`, ur_layers_elems() int32 words laid out [N][ceil(H/8)][ceil(W/8)][K][64][2]: per 8x8 tile, per depth
  * slot, per pixel, (packed face index, bits of the transmittance in front of that layer) of the layers that matter,
  * front to back, ended by face = -1.  Only the first few depth slots of a tile are ever touched.
- *   workspace: ur_workspace_bytes(total_faces) bytes; the backward must be given the SAME buffer, untouched.
+ *   workspace: ur_workspace_bytes(total_faces, N, H, W, K) bytes; the backward must be given the SAME buffer, untouched.
  *   grad_face_verts (NF,3,3) and grad_maps (N,Ht,Wt,3) must be zero-filled by the caller; either may be NULL
  *   (then that gradient is skipped).  The z column of grad_face_verts stays 0 (the layered blend never reads zbuf).
  */

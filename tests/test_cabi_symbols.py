@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in _header_symbols():
         assert hasattr(handle, name), name
     assert handle.ur_abi_version() >= 1
-    assert handle.ur_workspace_bytes(10) >= 10 * 96
+    assert handle.ur_workspace_bytes(10, 1, 8, 8, 1) >= 10 * 96
     assert handle.ur_last_error() is not None
 
 

@@ -165,4 +165,12 @@ __device__ __forceinline__ float layer_dalpha(float d, float a, bool valid, floa
   return a * (1.0f - a) * (-1.0f / sigma);
 }
 
+// true only if layer_alpha() == 1 exactly and layer_dalpha() == 0 for this signed distance (a sufficient test that
+// needs no exp): such a layer hides every layer behind it from the image and from all gradients.
+__device__ __forceinline__ bool hides_rest(float d, float sigma, int mode) {
+  if (mode == 0) return d <= 0.0f;
+  if (mode == 1) return d < 0.0f;           // exp(-0/sigma) == 1, clamp gradient 0
+  return d < -20.0f * sigma;                // exp(d/sigma) < 2^-25: 1/(1+e) rounds to 1, a(1-a) == 0
+}
+
 }  // namespace ur

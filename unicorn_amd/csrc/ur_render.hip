@@ -21,6 +21,8 @@
 
 using namespace ur;
 
+extern "C" size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K);
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -78,6 +80,8 @@ struct RasterParams {
   float blur;
   int clip;
   int nbx, nby;  // bins per row / column
+  int cap;       // K-list slots per lane held in LDS
+  unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
   // outputs (fragments)
   int32_t* p2f;
   float* zbuf;
@@ -112,12 +116,9 @@ __device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n
   return P.fuv + fl * 6;
 }
 
-constexpr int kBinCap = 1024;  // bin-list entries held in LDS per round
-
-template <int WPB> struct BinShape;
-template <> struct BinShape<4> { static constexpr int BW = 16, BH = 16; };
-template <> struct BinShape<2> { static constexpr int BW = 16, BH = 8; };
-template <> struct BinShape<1> { static constexpr int BW = 8, BH = 8; };
+constexpr int kBinCap = 1024;    // bin-list entries per scan round (256 per wave)
+constexpr int kSub = 64;         // faces staged in LDS per fine step
+constexpr int kLdsBudget = 81920;  // half of the CU's 160 KB: two workgroups per CU
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -130,16 +131,42 @@ __device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float
   return !(xc_hi < bb.x || xc_lo > bb.y || yc_hi < bb.z || yc_lo > bb.w);
 }
 
+__device__ __forceinline__ Face unpack_face(const float4 a, const float4 b, const float4 c, const float4 d,
+                                            const float4 e) {
+  Face f;
+  f.v0x = a.x; f.v0y = a.y; f.v1x = a.z; f.v1y = a.w;
+  f.v2x = b.x; f.v2y = b.y; f.z0 = b.z; f.z1 = b.w;
+  f.z2 = c.x; f.denom = c.y; f.l01 = c.z; f.l02 = c.w;
+  f.l12 = d.x; f.d01x = d.y; f.d01y = d.z; f.d12x = d.w;
+  f.d12y = e.x; f.d20x = e.y; f.d20y = e.z;
+  return f;
+}
+
+// The per-lane top-K list: the first `cap` slots live in LDS ([slot][lane], 8-byte lane stride: conflict free), the
+// rest (K > cap only, rare to be touched) in a global spill area of the same shape.
+struct KeyList {
+  unsigned long long* lds;    // + lane
+  unsigned long long* spill;  // + lane
+  int cap;
+  __device__ __forceinline__ unsigned long long get(int i) const {
+    return i < cap ? lds[(size_t)i * 64] : spill[(size_t)(i - cap) * 64];
+  }
+  __device__ __forceinline__ void put(int i, unsigned long long v) const {
+    if (i < cap) lds[(size_t)i * 64] = v; else spill[(size_t)(i - cap) * 64] = v;
+  }
+};
+
 // MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
-template <int WPB, int MODE>
-__global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
+template <int MODE>
+__global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BW = BinShape<WPB>::BW, BH = BinShape<WPB>::BH;
-  constexpr int NT = WPB * 64;
-  // LDS carve: [bin list: kBinCap int32][wave counts: 2*WPB int32 (+pad to 16 B)][keys: WPB * K * 64 u64]
+  constexpr int BW = 16, BH = 16, WPB = 4;
+  // LDS carve: [bin list 1024 i32][wave counts 16 i32][staged bbox 2x64 float4][staged records 2x320 float4][keys]
   int32_t* s_bin = reinterpret_cast<int32_t*>(smem);
   int32_t* s_wcnt = s_bin + kBinCap;
-  unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(smem + kBinCap * 4 + 64);
+  float4* s_bb = reinterpret_cast<float4*>(smem + kBinCap * 4 + 64);
+  float4* s_rec = s_bb + 2 * kSub;
+  unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(s_rec + 2 * kSub * 5);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bins_per_img = P.nbx * P.nby;
@@ -155,9 +182,7 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
   const float byc_hi = pix_to_ndc(H - 1 - by0, H, W), byc_lo = pix_to_ndc(H - 1 - by1, H, W);
 
   // this wave's tile
-  const int twx = (WPB == 4) ? (wave & 1) : (WPB == 2 ? wave : 0);
-  const int twy = (WPB == 4) ? (wave >> 1) : 0;
-  const int tx0 = bx0 + twx * kTile, ty0 = by0 + twy * kTile;
+  const int tx0 = bx0 + (wave & 1) * kTile, ty0 = by0 + (wave >> 1) * kTile;
   const bool tile_live = (tx0 < W) && (ty0 < H);
   const int tx1 = min(W, tx0 + kTile) - 1, ty1 = min(H, ty0 + kTile) - 1;
   const float txc_hi = pix_to_ndc(W - 1 - tx0, W, H), txc_lo = pix_to_ndc(W - 1 - max(tx1, tx0), W, H);
@@ -168,93 +193,130 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
   const bool pix_live = (x < W) && (y < H);
   const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
 
-  unsigned long long* keys = s_keys_all + (size_t)wave * K * 64;
+  const int64_t tile_id = ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * ((W + 7) / 8) + (tx0 >> 3);
+  KeyList keys;
+  keys.cap = P.cap;
+  keys.lds = s_keys_all + (size_t)wave * P.cap * 64 + lane;
+  keys.spill = P.spill + (tile_live ? tile_id : 0) * (int64_t)(K - P.cap) * 64 + lane;
   int cnt = 0;       // entries in this lane's list
   int tl_count = 0;  // MODE 1: faces appended to this tile's list (wave-uniform)
-  const int64_t tile_id = ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * ((W + 7) / 8) + (tx0 >> 3);
+  // MODE 2 only: depth of the nearest hit found so far that hides everything behind it (alpha == 1 and
+  // d(alpha)/d(dist) == 0).  A face whose nearest corner lies behind it cannot matter to this pixel's blend: its
+  // depth at the pixel is a convex combination of its corner depths (the clipped barycentrics are >= 0 and sum to 1).
+  float z_hide = __builtin_inff();
+  const bool can_cull = (MODE == 2) && (P.clip != 0 || P.blur == 0.0f);
 
   const int64_t f0 = P.first[n];
   const int nf = (int)P.nfaces[n];
 
-  int list_n = 0;
-  int it = 0;
-  for (int base = 0; base < nf; base += NT, ++it) {
-    // ---- coarse: append this chunk's survivors to the bin list, ascending --------------------------------------
-    if (base < nf) {
-      const int f = base + tid;
-      bool pass = false;
-      if (f < nf) pass = bbox_overlap(P.bbox[f0 + f], bxc_lo, bxc_hi, byc_lo, byc_hi);
-      const unsigned long long m = __ballot(pass);
-      if (lane == 0) s_wcnt[(it & 1) * WPB + wave] = __popcll(m);
-      __syncthreads();
-      int prefix = 0, total = 0;
+  for (int rbase = 0; rbase < nf; rbase += kBinCap) {
+    // ---- coarse: wave w scans faces [rbase + 256 w, +256) of this round, four independent bbox loads per lane; the
+    //      survivors of the four waves are then packed into one ascending bin list
+    const int wbase = rbase + wave * 256;
+    float4 bbv[4];
 #pragma unroll
-      for (int w = 0; w < WPB; ++w) {
-        const int c = s_wcnt[(it & 1) * WPB + w];
-        prefix += (w < wave) ? c : 0;
-        total += c;
-      }
-      if (pass) s_bin[list_n + prefix + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)(f0 + f);
-      list_n += total;
+    for (int q = 0; q < 4; ++q) {
+      const int f = wbase + q * 64 + lane;
+      bbv[q] = (f < nf) ? P.bbox[f0 + f] : make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
     }
-    const bool last = (base + NT >= nf);
-    if (!(last || list_n > kBinCap - NT)) continue;
-
-    // ---- fine: every wave consumes the bin list for its own tile -----------------------------------------------
+    int wc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool pass = bbox_overlap(bbv[q], bxc_lo, bxc_hi, byc_lo, byc_hi);
+      const unsigned long long m = __ballot(pass);
+      if (pass) s_bin[wave * 256 + wc + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)(f0 + wbase + q * 64 + lane);
+      wc += __popcll(m);
+    }
+    if (lane == 0) s_wcnt[wave] = wc;
     __syncthreads();
-    if (tile_live) {
-      for (int c0 = 0; c0 < list_n; c0 += 64) {
-        const int j = c0 + lane;
-        int fid = -1;
+    int prefix = 0, list_n = 0;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) {
+      const int c = s_wcnt[w];
+      prefix += (w < wave) ? c : 0;
+      list_n += c;
+    }
+    int e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = (q * 64 + lane < wc) ? s_bin[wave * 256 + q * 64 + lane] : -1;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q * 64 + lane < wc) s_bin[prefix + q * 64 + lane] = e[q];
+    __syncthreads();
+    if (list_n == 0) continue;
+
+    // ---- fine: 64 bin faces at a time; their bboxes / records are staged in LDS by the whole workgroup (next step's
+    //      global loads are in flight while this step is evaluated), each wave walks the ones that touch its tile
+    const int nsub = (list_n + kSub - 1) / kSub;
+    float4 r_bb = make_float4(0, 0, 0, 0), r_r0 = r_bb, r_r1 = r_bb;
+    auto stage_load = [&](int c) {
+      const int cntc = min(kSub, list_n - c * kSub);
+      if (tid < cntc) r_bb = P.bbox[s_bin[c * kSub + tid]];
+      if (tid < cntc * 5) r_r0 = P.rec[5 * (size_t)s_bin[c * kSub + tid / 5] + tid % 5];
+      if (tid + 256 < cntc * 5) r_r1 = P.rec[5 * (size_t)s_bin[c * kSub + (tid + 256) / 5] + (tid + 256) % 5];
+    };
+    auto stage_write = [&](int c) {
+      const int cntc = min(kSub, list_n - c * kSub);
+      float4* bb = s_bb + (c & 1) * kSub;
+      float4* rc = s_rec + (c & 1) * kSub * 5;
+      if (tid < cntc) bb[tid] = r_bb;
+      if (tid < cntc * 5) rc[tid] = r_r0;
+      if (tid + 256 < cntc * 5) rc[tid + 256] = r_r1;
+    };
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    for (int c = 0; c < nsub; ++c) {
+      if (c + 1 < nsub) stage_load(c + 1);
+      if (tile_live) {
+        const int cntc = min(kSub, list_n - c * kSub);
+        const float4* bbs = s_bb + (c & 1) * kSub;
+        const float4* rcs = s_rec + (c & 1) * kSub * 5;
         bool pass = false;
-        float4 bb = make_float4(0, 0, 0, 0);
-        if (j < list_n) {
-          fid = s_bin[j];
-          bb = P.bbox[fid];
-          pass = bbox_overlap(bb, txc_lo, txc_hi, tyc_lo, tyc_hi);
-        }
+        if (lane < cntc) pass = bbox_overlap(bbs[lane], txc_lo, txc_hi, tyc_lo, tyc_hi);
         unsigned long long m = __ballot(pass);
         if (MODE == 1) {
           if (pass) {
             const int pos = tl_count + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < P.tl_cap) P.tl_lists[tile_id * P.tl_cap + pos] = fid;
+            if (pos < P.tl_cap) P.tl_lists[tile_id * P.tl_cap + pos] = s_bin[c * kSub + lane];
           }
           tl_count += __popcll(m);
-          continue;
-        }
-        while (m) {
-          const int src = __builtin_ctzll(m);
-          m &= m - 1;
-          const int ufid = __builtin_amdgcn_readlane(fid, src);  // wave-uniform face id
-          const float4 ubb = make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.x), src)),
-                                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.y), src)),
-                                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.z), src)),
-                                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bb.w), src)));
-          const Face fc = load_face(P.rec, ufid);
-          bool hit = pix_live && !(px < ubb.x || px > ubb.y || py < ubb.z || py > ubb.w);
-          Eval ev;
-          if (hit) hit = eval_face(fc, px, py, P.blur, P.clip != 0, ev);
-          if (hit) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) | (unsigned)ufid;
-            if (cnt < K) {
-              keys[(size_t)cnt * 64 + lane] = key;
-              ++cnt;
-            } else {
-              // list full: replace the current maximum when the newcomer is smaller (rare path)
-              unsigned long long mx = 0;
-              int im = 0;
-              for (int i = 0; i < K; ++i) {
-                const unsigned long long kk = keys[(size_t)i * 64 + lane];
-                if (kk > mx) { mx = kk; im = i; }
+        } else {
+          while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const int ufid = s_bin[c * kSub + src];  // wave-uniform
+            const float4 ubb = bbs[src];
+            const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
+                                        rcs[src * 5 + 4]);
+            bool hit = pix_live && !(px < ubb.x || px > ubb.y || py < ubb.z || py > ubb.w);
+            if (can_cull) hit = hit && !(min_s(min_s(fc.z0, fc.z1), fc.z2) * 0.9999f > z_hide);
+            Eval ev;
+            if (hit) hit = eval_face(fc, px, py, P.blur, P.clip != 0, ev);
+            if (hit) {
+              if (MODE == 2 && hides_rest(ev.sd, P.sigma, P.mode)) z_hide = min_s(z_hide, ev.pz);
+              const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) | (unsigned)ufid;
+              if (cnt < K) {
+                keys.put(cnt, key);
+                ++cnt;
+              } else {
+                // list full: replace the current maximum when the newcomer is smaller (rare path)
+                unsigned long long mx = 0;
+                int im = 0;
+                for (int i = 0; i < K; ++i) {
+                  const unsigned long long kk = keys.get(i);
+                  if (kk > mx) { mx = kk; im = i; }
+                }
+                if (key < mx) keys.put(im, key);
               }
-              if (key < mx) keys[(size_t)im * 64 + lane] = key;
             }
           }
         }
       }
+      if (c + 1 < nsub) stage_write(c + 1);
+      __syncthreads();
     }
-    list_n = 0;
-    __syncthreads();
   }
 
   if (MODE == 1) {
@@ -281,7 +343,7 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
       if (act) {
         unsigned long long best = ~0ull;
         for (int i = 0; i < cnt; ++i) {
-          const unsigned long long kk = keys[(size_t)i * 64 + lane];
+          const unsigned long long kk = keys.get(i);
           if ((first_take || kk > last_key) && kk < best) best = kk;
         }
         last_key = best;
@@ -330,7 +392,7 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
     if (k < cnt) {
       unsigned long long best = ~0ull;
       for (int i = 0; i < cnt; ++i) {
-        const unsigned long long kk = keys[(size_t)i * 64 + lane];
+        const unsigned long long kk = keys.get(i);
         if ((first_take || kk > last_key) && kk < best) best = kk;
       }
       last_key = best;
@@ -365,44 +427,50 @@ __global__ void __launch_bounds__(WPB * 64) k_raster(const RasterParams P) {
   }
 }
 
-size_t raster_lds_bytes(int wpb, int K) { return (size_t)kBinCap * 4 + 64 + (size_t)wpb * K * 64 * 8; }
+constexpr size_t kRasterFixedLds = (size_t)kBinCap * 4 + 64 + 2 * kSub * 16 + 2 * kSub * 5 * 16;
 
-int pick_wpb(int K) {
-  const size_t budget = 160 * 1024;
-  if (raster_lds_bytes(4, K) <= budget) return 4;
-  if (raster_lds_bytes(2, K) <= budget) return 2;
-  if (raster_lds_bytes(1, K) <= budget) return 1;
-  return 0;
+// K-list slots per lane kept in LDS: all K when they fit two workgroups per CU, else what fits (the rest spills)
+int raster_cap(int K) {
+  const int fit = (int)((kLdsBudget - kRasterFixedLds) / (4 * 64 * 8));
+  return K < fit ? K : fit;
 }
 
-template <int WPB, int MODE> int launch_raster(RasterParams P, hipStream_t st) {
-  constexpr int BW = BinShape<WPB>::BW, BH = BinShape<WPB>::BH;
-  P.nbx = (P.W + BW - 1) / BW;
-  P.nby = (P.H + BH - 1) / BH;
-  const size_t lds = raster_lds_bytes(WPB, MODE == 1 ? 0 : P.K);
+size_t raster_spill_bytes(int N, int H, int W, int K) {
+  const int over = K - raster_cap(K);
+  return over <= 0 ? 0 : (size_t)N * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)over * 64 * 8;
+}
+
+template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
+  P.nbx = (P.W + 15) / 16;
+  P.nby = (P.H + 15) / 16;
+  P.cap = (MODE == 1) ? 1 : raster_cap(P.K);
+  const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static thread_local size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_raster<WPB, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_raster<MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
     configured = lds;
   }
   const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
-  hipLaunchKernelGGL((k_raster<WPB, MODE>), dim3((unsigned)blocks), dim3(WPB * 64), lds, st, P);
+  hipLaunchKernelGGL((k_raster<MODE>), dim3((unsigned)blocks), dim3(256), lds, st, P);
   return check_launch("k_raster");
 }
 
-int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, void* ws, size_t ws_bytes, hipStream_t st,
-               float4** bbox, float4** rec) {
-  if (ws_bytes < ur_workspace_bytes(NF)) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes,
-                                                     ur_workspace_bytes(NF));
-  if (reinterpret_cast<uintptr_t>(ws) & 15) return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
-  *bbox = reinterpret_cast<float4*>(ws);
-  *rec = *bbox + NF;
+// workspace = [bbox: NF float4][records: NF x 5 float4][K-list spill]
+int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, int N, int H, int W, int K, void* ws,
+               size_t ws_bytes, hipStream_t st, RasterParams& P) {
+  const size_t need = ur_workspace_bytes(NF, N, H, W, K);
+  if (ws_bytes < need) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+  float4* bbox = reinterpret_cast<float4*>(ws);
+  float4* rec = bbox + NF;
+  P.bbox = bbox; P.rec = rec;
+  P.spill = reinterpret_cast<unsigned long long*>(rec + 5 * NF);
   if (NF > 0) {
     hipLaunchKernelGGL(k_face_prep, dim3((unsigned)((NF + 255) / 256)), dim3(256), 0, st, face_verts, NF,
-                       sqrtf(blur), cull, *bbox, *rec);
+                       sqrtf(blur), cull, bbox, rec);
     return check_launch("k_face_prep");
   }
   return UR_OK;
@@ -983,9 +1051,10 @@ extern "C" {
 const char* ur_last_error(void) { return g_err; }
 int ur_abi_version(void) { return 1; }
 
-size_t ur_workspace_bytes(int64_t total_faces) {
-  // bbox (16 B) + record (80 B) per face, 16-byte granules
-  return (size_t)(total_faces < 1 ? 1 : total_faces) * 96;
+size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
+  // bbox (16 B) + record (80 B) per face, then the spill area of the per-pixel K-lists (only when K exceeds what
+  // LDS holds)
+  return (size_t)(total_faces < 1 ? 1 : total_faces) * 96 + raster_spill_bytes(N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
 }
 
 int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
@@ -1022,21 +1091,16 @@ int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face,
   if (!(blur_radius >= 0.0f)) return fail(UR_ERR_INVALID_ARG, "blur_radius must be >= 0");
   if (perspective_correct) return fail(UR_ERR_UNSUPPORTED, "perspective_correct=True is not supported");
   if (total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "more than 2^31-1 faces");
-  const int wpb = pick_wpb(K);
-  if (!wpb) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d does not fit the 160 KB LDS (max %d)", K,
-                        (int)((160 * 1024 - kBinCap * 4 - 64) / 512));
   if (N == 0) return UR_OK;
   hipStream_t st = (hipStream_t)stream;
-  float4 *bbox, *rec;
-  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, workspace, workspace_bytes, st, &bbox, &rec);
-  if (rc) return rc;
   RasterParams P{};
-  P.bbox = bbox; P.rec = rec; P.first = mesh_first_face; P.nfaces = mesh_num_faces;
+  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, N, H, W, K, workspace, workspace_bytes, st,
+                      P);
+  if (rc) return rc;
+  P.first = mesh_first_face; P.nfaces = mesh_num_faces;
   P.N = N; P.H = H; P.W = W; P.K = K; P.blur = blur_radius; P.clip = clip_barycentric_coords;
   P.p2f = pix_to_face; P.zbuf = zbuf; P.bary = bary; P.dists = dists;
-  if (wpb == 4) return launch_raster<4, 0>(P, st);
-  if (wpb == 2) return launch_raster<2, 0>(P, st);
-  return launch_raster<1, 0>(P, st);
+  return launch_raster<0>(P, st);
 }
 
 int ur_tile_faces(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
@@ -1047,14 +1111,14 @@ int ur_tile_faces(const float* face_verts, const int64_t* mesh_first_face, const
   if (N < 0 || H <= 0 || W <= 0 || cap <= 0 || total_faces < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
   if (N == 0) return UR_OK;
   hipStream_t st = (hipStream_t)stream;
-  float4 *bbox, *rec;
-  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, workspace, workspace_bytes, st, &bbox, &rec);
-  if (rc) return rc;
   RasterParams P{};
-  P.bbox = bbox; P.rec = rec; P.first = mesh_first_face; P.nfaces = mesh_num_faces;
+  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, N, H, W, 1, workspace, workspace_bytes, st,
+                      P);
+  if (rc) return rc;
+  P.first = mesh_first_face; P.nfaces = mesh_num_faces;
   P.N = N; P.H = H; P.W = W; P.K = 1; P.blur = blur_radius; P.clip = 0;
   P.tl_counts = counts; P.tl_lists = lists; P.tl_cap = cap;
-  return launch_raster<4, 1>(P, st);
+  return launch_raster<1>(P, st);
 }
 
 int ur_rasterize_meshes_backward(const float* face_verts, const int32_t* pix_to_face, const float* grad_zbuf,
@@ -1139,18 +1203,12 @@ int ur_render_layered_forward(const float* face_verts, const int64_t* mesh_first
   int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
                               face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
   if (rc) return rc;
-  const int wpb = pick_wpb(K);
-  if (!wpb) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d does not fit the 160 KB LDS (max %d)", K,
-                        (int)((160 * 1024 - kBinCap * 4 - 64) / 512));
   if (N == 0) return UR_OK;
   hipStream_t st = (hipStream_t)stream;
-  float4 *bbox, *rec;
-  rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, workspace, workspace_bytes, st, &bbox, &rec);
+  rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, N, H, W, K, workspace, workspace_bytes, st, P);
   if (rc) return rc;
-  P.bbox = bbox; P.rec = rec; P.image = image; P.layers = layers;
-  if (wpb == 4) return launch_raster<4, 2>(P, st);
-  if (wpb == 2) return launch_raster<2, 2>(P, st);
-  return launch_raster<1, 2>(P, st);
+  P.image = image; P.layers = layers;
+  return launch_raster<2>(P, st);
 }
 
 int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_first_face,
@@ -1162,7 +1220,7 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
                                float* grad_maps, void* stream) {
   if (!grad_image || !layers || !workspace) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
-  if (workspace_bytes < ur_workspace_bytes(total_faces)) return fail(UR_ERR_WORKSPACE, "workspace too small");
+  if (workspace_bytes < ur_workspace_bytes(total_faces, 0, H, W, K)) return fail(UR_ERR_WORKSPACE, "workspace too small");
   RasterParams P{};
   int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
                               face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);

@@ -21,7 +21,7 @@ _F3 = ctypes.c_float * 3
 _SIGNATURES = {
     "ur_last_error": (ctypes.c_char_p, []),
     "ur_abi_version": (_i, []),
-    "ur_workspace_bytes": (_sz, [_i64]),
+    "ur_workspace_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "ur_project_faces": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp]),
     "ur_project_faces_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ur_rasterize_meshes": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
@@ -126,12 +126,12 @@ class _on:
         return self._ctx.__exit__(*a)
 
 
-def workspace_bytes(total_faces):
-    return int(lib().ur_workspace_bytes(int(total_faces)))
+def workspace_bytes(total_faces, N, H, W, K):
+    return int(lib().ur_workspace_bytes(int(total_faces), int(N), int(H), int(W), int(K)))
 
 
-def _workspace(total_faces, device):
-    return torch.empty(workspace_bytes(total_faces), dtype=torch.uint8, device=device)
+def _workspace(total_faces, device, N, H, W, K):
+    return torch.empty(workspace_bytes(total_faces, N, H, W, K), dtype=torch.uint8, device=device)
 
 
 def _faces_layout(faces, N):
@@ -182,7 +182,7 @@ def rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, bl
     zbuf = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if want_zbuf else None
     bary = torch.empty(N, H, W, K, 3, dtype=torch.float32, device=dev) if want_bary else None
     dists = torch.empty(N, H, W, K, dtype=torch.float32, device=dev) if want_dists else None
-    ws = _workspace(NF, dev)
+    ws = _workspace(NF, dev, N, H, W, K)
     with _on(face_verts), _timed("ur_rasterize_meshes", face_verts):
         _check(lib().ur_rasterize_meshes(_ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64),
                                          _ptr(mesh_num_faces, torch.int64), N, NF, H, W, float(blur_radius), K,
@@ -215,7 +215,7 @@ def tile_faces(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_rad
     TH, TW = (H + 7) // 8, (W + 7) // 8
     counts = torch.empty(N, TH, TW, dtype=torch.int32, device=dev)
     lists = torch.empty(N, TH, TW, cap, dtype=torch.int32, device=dev)
-    ws = _workspace(NF, dev)
+    ws = _workspace(NF, dev, N, H, W, 1)
     with _on(face_verts), _timed("ur_tile_faces", face_verts):
         _check(lib().ur_tile_faces(_ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64),
                                    _ptr(mesh_num_faces, torch.int64), N, NF, H, W, float(blur_radius),
@@ -274,7 +274,7 @@ def render_layered_forward(face_verts, mesh_first_face, mesh_num_faces, image_si
     dev = face_verts.device
     image = torch.empty(N, 4, H, W, dtype=torch.float32, device=dev)
     layers = torch.empty(int(lib().ur_layers_elems(N, H, W, K)), dtype=torch.int32, device=dev)
-    ws = _workspace(NF, dev)
+    ws = _workspace(NF, dev, N, H, W, K)
     with _on(face_verts), _timed("ur_render_layered_forward", face_verts):
         _check(lib().ur_render_layered_forward(
             _ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64), _ptr(mesh_num_faces, torch.int64), N,
