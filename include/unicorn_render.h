@@ -123,14 +123,16 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
  *           the autograd of both (trainer.py:151).  Numerically identical to ur_rasterize_meshes + ur_shade_blend:
  * the blend stops at the first layer that hides everything behind it (alpha == 1 with zero d(alpha)/d(dist)), which
  * changes neither the image nor any gradient.  No (N,H,W,K) fragment tensors are materialised: the forward leaves
- * only `layers`, ur_layers_elems() int32 words laid out [N][ceil(H/8)][ceil(W/8)][K][64][2]: per 8x8 tile, per depth
- * slot, per pixel, (packed face index, bits of the transmittance in front of that layer) of the layers that matter,
- * front to back, ended by face = -1.  Only the first few depth slots of a tile are ever touched.
+ * only `layers`, ur_layers_elems() int32 words laid out [N][ceil(H/8)][ceil(W/8)][K][6][64]: per 8x8 tile, per depth
+ * slot, six 64-pixel planes (packed face index; float bits of the transmittance in front of the layer, its alpha and
+ * its colour) of the layers that matter, front to back, ended by face = -1.  Only the first few depth slots of a tile
+ * are ever touched.  The backward also needs ur_backward_scratch_bytes() of uninitialised device scratch.
  *   workspace: ur_workspace_bytes(total_faces, N, H, W, K) bytes; the backward must be given the SAME buffer, untouched.
  *   grad_face_verts (NF,3,3) and grad_maps (N,Ht,Wt,3) must be zero-filled by the caller; either may be NULL
  *   (then that gradient is skipped).  The z column of grad_face_verts stays 0 (the layered blend never reads zbuf).
  */
 size_t ur_layers_elems(int N, int H, int W, int K);
+size_t ur_backward_scratch_bytes(int N, int H, int W, int K);
 
 int ur_render_layered_forward(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces,
                               int N, int64_t total_faces, int H, int W, float blur_radius, int K,
@@ -144,8 +146,8 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
                                float blur_radius, int K, int clip_barycentric_coords, const float* maps,
                                const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
                                const float* background, const float* ambient, int mode, const int32_t* layers,
-                               const void* workspace, size_t workspace_bytes, float* grad_face_verts,
-                               float* grad_maps, void* stream);
+                               const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                               float* grad_face_verts, float* grad_maps, void* stream);
 
 #ifdef __cplusplus
 }

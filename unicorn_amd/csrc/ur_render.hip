@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/unicorn_render.h"
 #include "ur_device.h"
@@ -45,7 +46,8 @@ int check_launch(const char* what) {
 // face records
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv, int64_t NF, float r, int cull,
-                                                   float4* __restrict__ bbox, float4* __restrict__ rec) {
+                                                   float4* __restrict__ bbox, float4* __restrict__ rec,
+                                                   float* __restrict__ fz) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NF) return;
   const float* p = fv + i * 9;
@@ -57,6 +59,7 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
   float ylo = min_s(min_s(v0y, v1y), v2y) - r, yhi = max_s(max_s(v0y, v1y), v2y) + r;
   if (culled) { xlo = __builtin_inff(); xhi = -__builtin_inff(); }
   bbox[i] = make_float4(xlo, xhi, ylo, yhi);
+  fz[i] = min_s(min_s(z0, z1), z2);
   const float denom = ((v2x - v0x) * (v1y - v0y) - (v2y - v0y) * (v1x - v0x)) + kEps;  // edge(v2; v0, v1) + eps
   const float d01x = v1x - v0x, d01y = v1y - v0y, d12x = v2x - v1x, d12y = v2y - v1y, d20x = v0x - v2x,
               d20y = v0y - v2y;
@@ -75,12 +78,14 @@ struct RasterParams {
   const float4* bbox;
   const float4* rec;
   const int64_t* first;
+  const float* fz;  // nearest corner depth per face
   const int64_t* nfaces;
   int N, H, W, K;
   float blur;
   int clip;
   int nbx, nby;  // bins per row / column
   int cap;       // K-list slots per lane held in LDS
+  int dbg;       // development only (UR_DEBUG env): 1 = skip the per-pixel evaluation, 2 = skip shading
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
   // outputs (fragments)
   int32_t* p2f;
@@ -102,9 +107,11 @@ struct RasterParams {
   int use_amb;
   int mode;
   float* image;     // (N,4,H,W)
-  int32_t* layers;  // int2 [N][TH][TW][K][64]: per tile, per depth slot, per lane (= pixel): (face, bits of the
-                    // transmittance in front of it) of the layers that matter for the blend, front to back, ended
-                    // by face = -1 (unless all K slots are used)
+  int32_t* layers;  // [N][TH][TW][K][6][64]: per tile, per depth slot, six 64-lane planes (lane = pixel): face index,
+                    // transmittance in front of the layer, alpha, colour r g b (float bits) of the layers that
+                    // matter for the blend, front to back, ended by face = -1 (unless all K slots are used)
+  float* scratch;   // backward: [N][TH][TW][K][2][64] per-layer (dL/dalpha, weight) handed from the per-pixel sweep
+                    // to the evenly dealt gradient pass
   const float* gimage;
   float* gmaps;
   float* gfv;
@@ -118,7 +125,7 @@ __device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n
 
 constexpr int kBinCap = 1024;    // bin-list entries per scan round (256 per wave)
 constexpr int kSub = 64;         // faces staged in LDS per fine step
-constexpr int kLdsBudget = 81920;  // half of the CU's 160 KB: two workgroups per CU
+constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -142,6 +149,9 @@ __device__ __forceinline__ Face unpack_face(const float4 a, const float4 b, cons
   return f;
 }
 
+// A key packs (depth bits, face index, hides-the-rest flag): unsigned order == (depth, face) order (depths are >= +0).
+__device__ __forceinline__ int key_face(unsigned long long k) { return (int)(((unsigned)(k & 0xffffffffull)) >> 1); }
+
 // The per-lane top-K list: the first `cap` slots live in LDS ([slot][lane], 8-byte lane stride: conflict free), the
 // rest (K > cap only, rare to be touched) in a global spill area of the same shape.
 struct KeyList {
@@ -161,10 +171,11 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BW = 16, BH = 16, WPB = 4;
-  // LDS carve: [bin list 1024 i32][wave counts 16 i32][staged bbox 2x64 float4][staged records 2x320 float4][keys]
+  // LDS carve: [bin list 1024 i32][wave counts 16 i32][item prefix 4x64 i32][staged bbox 2x64 float4]
+  //            [staged records 2x320 float4][keys]
   int32_t* s_bin = reinterpret_cast<int32_t*>(smem);
   int32_t* s_wcnt = s_bin + kBinCap;
-  float4* s_bb = reinterpret_cast<float4*>(smem + kBinCap * 4 + 64);
+  float4* s_bb = reinterpret_cast<float4*>(smem + kBinCap * 4 + 64 + 1024);
   float4* s_rec = s_bb + 2 * kSub;
   unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(s_rec + 2 * kSub * 5);
 
@@ -204,45 +215,91 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
   // d(alpha)/d(dist) == 0).  A face whose nearest corner lies behind it cannot matter to this pixel's blend: its
   // depth at the pixel is a convex combination of its corner depths (the clipped barycentrics are >= 0 and sum to 1).
   float z_hide = __builtin_inff();
+  unsigned long long hide_key = ~0ull;  // smallest key among the hits that hide the rest
+  bool stale = false;                   // hide_key moved since this lane's list was last compacted
   const bool can_cull = (MODE == 2) && (P.clip != 0 || P.blur == 0.0f);
 
   const int64_t f0 = P.first[n];
   const int nf = (int)P.nfaces[n];
 
   for (int rbase = 0; rbase < nf; rbase += kBinCap) {
-    // ---- coarse: wave w scans faces [rbase + 256 w, +256) of this round, four independent bbox loads per lane; the
-    //      survivors of the four waves are then packed into one ascending bin list
+    // ---- coarse: wave w scans faces [rbase + 256 w, +256) of this round (independent bbox loads per lane).  The
+    //      survivors are packed into one bin list, nearer half first (by nearest-corner depth against the midpoint of
+    //      the bin's depth range), ascending face index inside each half: the fused blend can then skip most of the
+    //      far side of a closed mesh (z_hide below).  Order never changes results -- selection is by (depth, face).
     const int wbase = rbase + wave * 256;
     float4 bbv[4];
+    float zv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int f = wbase + q * 64 + lane;
       bbv[q] = (f < nf) ? P.bbox[f0 + f] : make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
+      zv[q] = (MODE == 2 && f < nf) ? P.fz[f0 + f] : 0.0f;
     }
+    unsigned long long pm[4];
     int wc = 0;
+    float zlo = __builtin_inff(), zhi = -__builtin_inff();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool pass = bbox_overlap(bbv[q], bxc_lo, bxc_hi, byc_lo, byc_hi);
-      const unsigned long long m = __ballot(pass);
-      if (pass) s_bin[wave * 256 + wc + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)(f0 + wbase + q * 64 + lane);
-      wc += __popcll(m);
+      pm[q] = __ballot(pass);
+      wc += __popcll(pm[q]);
+      if (MODE == 2 && pass) { zlo = min_s(zlo, zv[q]); zhi = max_s(zhi, zv[q]); }
     }
-    if (lane == 0) s_wcnt[wave] = wc;
+    if (MODE == 2) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        zlo = fminf(zlo, __shfl_xor(zlo, off, 64));
+        zhi = fmaxf(zhi, __shfl_xor(zhi, off, 64));
+      }
+    }
+    if (lane == 0) {
+      s_wcnt[wave] = wc;
+      s_wcnt[8 + wave] = __float_as_int(zlo);
+      s_wcnt[12 + wave] = __float_as_int(zhi);
+    }
     __syncthreads();
-    int prefix = 0, list_n = 0;
+    float zmid = __builtin_inff();
+    if (MODE == 2) {
+      float a = __builtin_inff(), b2 = -__builtin_inff();
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) {
+        a = fminf(a, __int_as_float(s_wcnt[8 + w]));
+        b2 = fmaxf(b2, __int_as_float(s_wcnt[12 + w]));
+      }
+      zmid = 0.5f * (a + b2);
+    }
+    unsigned long long nm[4];  // passing faces of the near half
+    int wn = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      nm[q] = (MODE == 2) ? __ballot(((pm[q] >> lane) & 1ull) && zv[q] <= zmid) : pm[q];
+      wn += __popcll(nm[q]);
+    }
+    if (lane == 0) s_wcnt[4 + wave] = wn;
+    __syncthreads();
+    int list_n = 0, near_n = 0, pre_all = 0, pre_near = 0;
 #pragma unroll
     for (int w = 0; w < WPB; ++w) {
-      const int c = s_wcnt[w];
-      prefix += (w < wave) ? c : 0;
+      const int c = s_wcnt[w], cn = s_wcnt[4 + w];
+      pre_all += (w < wave) ? c : 0;
+      pre_near += (w < wave) ? cn : 0;
       list_n += c;
+      near_n += cn;
     }
-    int e[4];
+    {
+      int pos_near = pre_near, pos_far = near_n + (pre_all - pre_near);
+      const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) e[q] = (q * 64 + lane < wc) ? s_bin[wave * 256 + q * 64 + lane] : -1;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q * 64 + lane < wc) s_bin[prefix + q * 64 + lane] = e[q];
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long fm = pm[q] & ~nm[q];
+        const int fid = (int32_t)(f0 + wbase + q * 64 + lane);
+        if ((nm[q] >> lane) & 1ull) s_bin[pos_near + __popcll(nm[q] & lt)] = fid;
+        else if ((fm >> lane) & 1ull) s_bin[pos_far + __popcll(fm & lt)] = fid;
+        pos_near += __popcll(nm[q]);
+        pos_far += __popcll(fm);
+      }
+    }
     __syncthreads();
     if (list_n == 0) continue;
 
@@ -283,6 +340,7 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
           }
           tl_count += __popcll(m);
         } else {
+          if (P.dbg == 1) m = 0;
           while (m) {
             const int src = __builtin_ctzll(m);
             m &= m - 1;
@@ -293,11 +351,26 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
             bool hit = pix_live && !(px < ubb.x || px > ubb.y || py < ubb.z || py > ubb.w);
             if (can_cull) hit = hit && !(min_s(min_s(fc.z0, fc.z1), fc.z2) * 0.9999f > z_hide);
             Eval ev;
+            if (P.dbg == 3) hit = false;
             if (hit) hit = eval_face(fc, px, py, P.blur, P.clip != 0, ev);
             if (hit) {
-              if (MODE == 2 && hides_rest(ev.sd, P.sigma, P.mode)) z_hide = min_s(z_hide, ev.pz);
-              const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) | (unsigned)ufid;
-              if (cnt < K) {
+              const bool hides = (MODE == 2) && hides_rest(ev.sd, P.sigma, P.mode);
+              const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
+                                             ((unsigned)ufid << 1) | (hides ? 1u : 0u);
+              if (hides && key < hide_key) { z_hide = ev.pz; hide_key = key; stale = true; }
+              if (MODE == 2 && P.dbg != 5 && stale && cnt >= P.cap && key <= hide_key) {
+                // about to leave LDS (or full): first throw out what the nearest hiding hit has made irrelevant
+                int j = 0;
+                for (int i = 0; i < cnt; ++i) {
+                  const unsigned long long kk = keys.get(i);
+                  if (kk <= hide_key) { keys.put(j, kk); ++j; }
+                }
+                cnt = j;
+                stale = false;
+              }
+              if (MODE == 2 && key > hide_key) {
+                // behind a hit that hides the rest: irrelevant to the blend
+              } else if (cnt < K) {
                 keys.put(cnt, key);
                 ++cnt;
               } else {
@@ -329,56 +402,135 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
   if (!tile_live) return;
 
   if (MODE == 2) {
-    // ---- fused shading: walk this pixel's hits front to back, blend, stop at the first layer that hides the rest
+    // ---- fused shading.  (a) per pixel: drop the hits behind the nearest one that hides the rest, sort what is left
+    //      front to back (in place; that hit, if any, comes last);  (b) the (pixel, layer) items of the whole tile
+    //      are dealt out evenly over the 64 lanes -- any lane can evaluate any item -- so every lane stays busy
+    //      although pixels have very different depths;  (c) each pixel pulls its items' (alpha, colour) back from
+    //      the lanes that computed them, in depth order, and composites: the arithmetic and its order are exactly
+    //      those of a per-pixel loop, so the image is bit-identical to the two-stage path.
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
-    int2* lay = reinterpret_cast<int2*>(P.layers) + tile_id * (int64_t)K * 64 + lane;
-    float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
-    unsigned long long last_key = 0;
-    bool first_take = true;
-    bool done = !pix_live;
-    int depth = 0;
-    while (true) {
-      const bool act = !done && depth < cnt;
-      if (!__any(act)) break;
-      if (act) {
-        unsigned long long best = ~0ull;
-        for (int i = 0; i < cnt; ++i) {
+    unsigned long long* lds_base = s_keys_all + (size_t)wave * P.cap * 64;
+    unsigned long long* spill_base = P.spill + tile_id * (int64_t)(K - P.cap) * 64;
+    int n_rel = cnt;
+    if (__any(hide_key != ~0ull && cnt > 0)) {
+      const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(hide_key != ~0ull ? cnt : 0));
+      int j = 0;
+      for (int i = 0; i < maxcnt; ++i)
+        if (i < cnt && hide_key != ~0ull) {
           const unsigned long long kk = keys.get(i);
-          if ((first_take || kk > last_key) && kk < best) best = kk;
+          if (kk <= hide_key) { keys.put(j, kk); ++j; }
         }
-        last_key = best;
-        first_take = false;
-        const int fid = (int)(unsigned)(best & 0xffffffffull);
+      if (hide_key != ~0ull) n_rel = j;
+    }
+    if (!pix_live || P.dbg == 2) n_rel = 0;
+    constexpr int kDeep = 8;
+    {
+      // short lists: per-lane selection sort
+      const bool mine = n_rel <= kDeep || n_rel > 64;
+      int sorted = 0;
+      while (__any(mine && sorted < n_rel - 1)) {
+        if (mine && sorted < n_rel - 1) {
+          unsigned long long best = keys.get(sorted);
+          const unsigned long long cur = best;
+          int ib = sorted;
+          for (int i = sorted + 1; i < n_rel; ++i) {
+            const unsigned long long kk = keys.get(i);
+            if (kk < best) { best = kk; ib = i; }
+          }
+          if (ib != sorted) { keys.put(ib, cur); keys.put(sorted, best); }
+          ++sorted;
+        }
+      }
+      // long lists (pixels in the blur halo of a silhouette vertex): the whole wave sorts one list at a time by
+      // rank counting -- lane j holds entry j, the list is broadcast entry by entry, no memory access in the loop
+      unsigned long long deep = __ballot(!mine);
+      while (deep) {
+        const int l = __builtin_ctzll(deep);
+        deep &= deep - 1;
+        const int ml = __builtin_amdgcn_readlane(n_rel, l);
+        unsigned long long kj = ~0ull;
+        if (lane < ml)
+          kj = (lane < P.cap) ? lds_base[(size_t)lane * 64 + l] : spill_base[(size_t)(lane - P.cap) * 64 + l];
+        const unsigned lo = (unsigned)kj, hi = (unsigned)(kj >> 32);
+        int rank = 0;
+        for (int i = 0; i < ml; ++i) {
+          const unsigned long long ki = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, i) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)lo, i);
+          rank += (ki < kj) ? 1 : 0;
+        }
+        if (lane < ml) {
+          if (rank < P.cap) lds_base[(size_t)rank * 64 + l] = kj;
+          else spill_base[(size_t)(rank - P.cap) * 64 + l] = kj;
+        }
+      }
+    }
+    if (P.dbg == 4) n_rel = 0;
+    const int m = n_rel;  // layers of this pixel that matter, front to back in slots [0, m)
+    int incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    const int pre = incl - m;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int* s_pre = s_wcnt + 16 + wave * 64;
+    s_pre[lane] = pre;
+    int32_t* lay = P.layers + tile_id * (int64_t)K * 6 * 64 + lane;  // [K][6 words][64 lanes]
+    float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+    for (int base = 0; base < total; base += 64) {
+      const int item = base + lane;
+      float va = 0.0f, vr = 0.0f, vg = 0.0f, vb = 0.0f;
+      if (item < total) {
+        int l = 0;  // owner: the last lane whose first item is <= item
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (s_pre[l + step] <= item) l += step;
+        const int k = item - s_pre[l];
+        const unsigned long long key = (k < P.cap) ? lds_base[(size_t)k * 64 + l]
+                                                    : spill_base[(size_t)(k - P.cap) * 64 + l];
+        const int fid = key_face(key);
+        const float qx = pix_to_ndc(W - 1 - (tx0 + (l & 7)), W, H), qy = pix_to_ndc(H - 1 - (ty0 + (l >> 3)), H, W);
         const Face fc = load_face(P.rec, fid);
         Eval ev;
-        eval_face(fc, px, py, P.blur, P.clip != 0, ev);
-        const float a = layer_alpha(ev.sd, true, P.sigma, P.mode);
+        eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
+        va = layer_alpha(ev.sd, true, P.sigma, P.mode);
         const float* fu = face_uv_row(P, n, fid);
         const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
         const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
         const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
-        float cr, cg, cb;
-        sample_rgb(map, bl, P.Ht, P.Wt, cr, cg, cb);
-        if (P.use_amb) { cr *= P.amb[0]; cg *= P.amb[1]; cb *= P.amb[2]; }
-        lay[(int64_t)depth * 64] = make_int2(fid, __float_as_int(occ));
-        r += occ * a * cr; g += occ * a * cg; b += occ * a * cb;
-        occ = occ * (1.0f - a);
-        ++depth;
-        // everything behind contributes exactly 0 to the image, and to the gradients as long as d(alpha)/d(dist)
-        // of this layer is 0 too (otherwise the backward needs what lies behind it)
-        done = (occ == 0.0f) && (layer_dalpha(ev.sd, a, true, P.sigma, P.mode) == 0.0f);
+        sample_rgb(map, bl, P.Ht, P.Wt, vr, vg, vb);
+        if (P.use_amb) { vr *= P.amb[0]; vg *= P.amb[1]; vb *= P.amb[2]; }
+      }
+      // owners composite their items of this batch, in depth order
+      const int s0 = max(pre, base), e0 = min(pre + m, base + 64);
+      const int nloop = __builtin_amdgcn_readfirstlane(wave_max(e0 - s0));
+      for (int t = 0; t < nloop; ++t) {
+        const int src = (s0 + t - base) & 63;
+        const float a = __shfl(va, src, 64), cr = __shfl(vr, src, 64), cg = __shfl(vg, src, 64),
+                    cb = __shfl(vb, src, 64);
+        if (s0 + t < e0) {
+          const int kk = s0 + t - pre;
+          int32_t* le = lay + (int64_t)kk * 6 * 64;
+          le[0] = key_face(keys.get(kk));
+          le[64] = __float_as_int(occ);
+          le[128] = __float_as_int(a);
+          le[192] = __float_as_int(cr);
+          le[256] = __float_as_int(cg);
+          le[320] = __float_as_int(cb);
+          r += occ * a * cr; g += occ * a * cg; b += occ * a * cb;
+          occ = occ * (1.0f - a);
+        }
       }
     }
+    if (m < K) lay[(int64_t)m * 6 * 64] = -1;
     if (pix_live) {
-      if (depth < K) lay[(int64_t)depth * 64] = make_int2(-1, 0);
       const int64_t hw = (int64_t)H * W;
       float* img = P.image + (int64_t)n * 4 * hw + (int64_t)y * W + x;
       img[0] = r + occ * 1.0f * P.bg[0];
       img[hw] = g + occ * 1.0f * P.bg[1];
       img[2 * hw] = b + occ * 1.0f * P.bg[2];
       img[3 * hw] = 1.0f - occ;
-    } else {
-      lay[0] = make_int2(-1, 0);
     }
     return;
   }
@@ -397,7 +549,7 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
       }
       last_key = best;
       first_take = false;
-      const int fid = (int)(unsigned)(best & 0xffffffffull);
+      const int fid = key_face(best);
       const Face fc = load_face(P.rec, fid);
       Eval ev;
       eval_face(fc, px, py, P.blur, P.clip != 0, ev);
@@ -427,11 +579,12 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
   }
 }
 
-constexpr size_t kRasterFixedLds = (size_t)kBinCap * 4 + 64 + 2 * kSub * 16 + 2 * kSub * 5 * 16;
+constexpr size_t kRasterFixedLds = (size_t)kBinCap * 4 + 64 + 1024 + 2 * kSub * 16 + 2 * kSub * 5 * 16;
 
 // K-list slots per lane kept in LDS: all K when they fit two workgroups per CU, else what fits (the rest spills)
 int raster_cap(int K) {
-  const int fit = (int)((kLdsBudget - kRasterFixedLds) / (4 * 64 * 8));
+  int fit = (int)((kLdsBudget - kRasterFixedLds) / (4 * 64 * 8));
+  if (const char* e = getenv("UR_CAP")) fit = atoi(e);  // development only
   return K < fit ? K : fit;
 }
 
@@ -444,6 +597,7 @@ template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
   P.cap = (MODE == 1) ? 1 : raster_cap(P.K);
+  { const char* d = getenv("UR_DEBUG"); P.dbg = d ? atoi(d) : 0; }
   const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static thread_local size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
@@ -458,7 +612,7 @@ template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
   return check_launch("k_raster");
 }
 
-// workspace = [bbox: NF float4][records: NF x 5 float4][K-list spill]
+// workspace = [bbox: NF float4][records: NF x 5 float4][nearest depth: NF float, padded to 16 B][K-list spill]
 int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, int N, int H, int W, int K, void* ws,
                size_t ws_bytes, hipStream_t st, RasterParams& P) {
   const size_t need = ur_workspace_bytes(NF, N, H, W, K);
@@ -466,11 +620,12 @@ int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, int N,
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
   float4* bbox = reinterpret_cast<float4*>(ws);
   float4* rec = bbox + NF;
-  P.bbox = bbox; P.rec = rec;
-  P.spill = reinterpret_cast<unsigned long long*>(rec + 5 * NF);
+  float* fz = reinterpret_cast<float*>(rec + 5 * NF);
+  P.bbox = bbox; P.rec = rec; P.fz = fz;
+  P.spill = reinterpret_cast<unsigned long long*>(fz + ((NF + 3) / 4) * 4);
   if (NF > 0) {
     hipLaunchKernelGGL(k_face_prep, dim3((unsigned)((NF + 255) / 256)), dim3(256), 0, st, face_verts, NF,
-                       sqrtf(blur), cull, bbox, rec);
+                       sqrtf(blur), cull, bbox, rec, fz);
     return check_launch("k_face_prep");
   }
   return UR_OK;
@@ -586,11 +741,15 @@ __global__ void __launch_bounds__(256) k_raster_bwd(const float* __restrict__ fv
 // fused backward of the layered render: grad_image -> grad_face_verts (xy only: the layered blend never reads zbuf),
 // grad_maps.  Same decomposition as the forward: workgroup = 16x16 bin, wave = 8x8 tile, lane = pixel.
 //
-// With occ_k = prod_{j<k}(1-a_j) (saved by the forward next to the face index), behind_k = colour composited from
-// the layers behind k, dotted with the RGB cotangent g, and trans_k = prod_{j>k}(1-a_j):
+// With occ_k = prod_{j<k}(1-a_j), behind_k = colour composited from the layers behind k, dotted with the RGB
+// cotangent g, and trans_k = prod_{j>k}(1-a_j):
 //     dL/dcolour_k = occ_k a_k g                          -> texture scatter + uv -> barycentrics -> vertex xy
 //     dL/da_k      = occ_k (c_k.g - behind_k) + g_A occ_k trans_k            -> signed distance -> vertex xy
-// so ONE back-to-front sweep over the list has everything it needs; nothing is parked per layer.
+// Step (a): each pixel sweeps its list back to front using (occ, alpha, colour) the forward saved per layer -- a
+// few flops per layer, no geometry -- and leaves (dL/dalpha_k, occ_k a_k) in a scratch array.  Step (b): the
+// expensive part (re-evaluating the face at the pixel, bilinear footprint, chain rule to the vertices) is done per
+// (pixel, layer) ITEM, the tile's items dealt out evenly over the 64 lanes, so lanes stay busy whatever the depth
+// distribution over pixels is.
 //
 // Scatter: instead of one global float atomic per (pixel, layer, component) -- 64 lanes hitting 64 different faces /
 // texture rows, the slowest shape for the memory-side atomic units -- the workgroup first sums in two small LDS
@@ -636,6 +795,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   __shared__ float s_fval[kFaceSlots * 6];
   __shared__ int s_ttag[kTexSlots];
   __shared__ float s_tval[kTexSlots * 3];
+  __shared__ int s_pre_all[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
   for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0f;
@@ -653,76 +813,108 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   const bool tile_live = (tx0 < W) && (ty0 < H);
   const int x = tx0 + (lane & 7), y = ty0 + (lane >> 3);
   const bool live = (x < W) && (y < H);
-  const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
   const int64_t tile_id = ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * TW + (tx0 >> 3);
-  const int2* lay = reinterpret_cast<const int2*>(P.layers) + (tile_live ? tile_id : 0) * (int64_t)K * 64 + lane;
+  const int32_t* lay_tile = P.layers + (tile_live ? tile_id : 0) * (int64_t)K * 6 * 64;  // [K][6][64]
+  const int32_t* lay = lay_tile + lane;
+  float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 2 * 64;         // [K][2][64]
   float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
 
-  int depth = 0;
+  int m = 0;  // this pixel's layer count
   if (tile_live) {
     bool alive = live;
     for (int k = 0; k < K; ++k) {
-      if (alive) alive = lay[(int64_t)k * 64].x >= 0;
+      if (alive) alive = lay[(int64_t)k * 6 * 64] >= 0;
       if (!__any(alive)) break;
-      depth += alive ? 1 : 0;
+      m += alive ? 1 : 0;
     }
   }
-  const int maxdepth = __builtin_amdgcn_readfirstlane(wave_max(depth));
+  const int maxm = __builtin_amdgcn_readfirstlane(wave_max(m));
 
-  if (maxdepth > 0) {
+  if (maxm > 0) {
     const int64_t hw = (int64_t)H * W;
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
     if (live) {
       const float* gi = P.gimage + (int64_t)n * 4 * hw + (int64_t)y * W + x;
       g0 = gi[0]; g1 = gi[hw]; g2 = gi[2 * hw]; g3 = gi[3 * hw];
     }
+    // ---- (a) per pixel, back to front, from what the forward saved: dL/dalpha_k and the colour weight occ_k a_k
+    {
+      float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+      float trans = 1.0f;
+      for (int k = maxm - 1; k >= 0; --k) {
+        if (k >= m) continue;
+        const int32_t* le = lay + (int64_t)k * 6 * 64;
+        const float occ = __int_as_float(le[64]), a = __int_as_float(le[128]);
+        const float cr = __int_as_float(le[192]), cgc = __int_as_float(le[256]), cb = __int_as_float(le[320]);
+        const float cg = g0 * cr + g1 * cgc + g2 * cb;
+        const float ga = occ * (cg - behind) + g3 * occ * trans;
+        float* sc = scr_tile + (int64_t)k * 2 * 64 + lane;
+        sc[0] = ga;
+        sc[64] = occ * a;
+        behind = a * cg + (1.0f - a) * behind;
+        trans = trans * (1.0f - a);
+      }
+    }
+    // ---- (b) the tile's (pixel, layer) items dealt out evenly over the lanes: geometry is re-evaluated once per
+    //      item, gradients go to the LDS tables
+    int incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    const int pre = incl - m;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int* s_pre = s_pre_all + wave * 64;
+    s_pre[lane] = pre;
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
     const bool clip = P.clip != 0;
-    float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
-    float trans = 1.0f;
-    for (int k = maxdepth - 1; k >= 0; --k) {
-      if (k >= depth) continue;
-      const int2 le = lay[(int64_t)k * 64];
-      const int fid = le.x;
-      const float occ = __int_as_float(le.y);
+    for (int base = 0; base < total; base += 64) {
+      const int item = base + lane;
+      int l = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1)
+        if (s_pre[l + step] <= item) l += step;
+      if (item >= total) l = lane;
+      // cotangent of the owner pixel (all lanes take part in the shuffles)
+      const float q0 = __shfl(g0, l, 64), q1 = __shfl(g1, l, 64), q2 = __shfl(g2, l, 64);
+      if (item >= total) continue;
+      const int k = item - s_pre[l];
+      const int32_t* le = lay_tile + (int64_t)k * 6 * 64 + l;
+      const int fid = le[0];
+      const float a = __int_as_float(le[128]);
+      const float ga = scr_tile[(int64_t)k * 2 * 64 + l], wgt = scr_tile[(int64_t)k * 2 * 64 + 64 + l];
+      const float px = pix_to_ndc(W - 1 - (tx0 + (l & 7)), W, H), py = pix_to_ndc(H - 1 - (ty0 + (l >> 3)), H, W);
       const Face fc = load_face(P.rec, fid);
       Eval ev;
       eval_face(fc, px, py, P.blur, clip, ev);
-      const float a = layer_alpha(ev.sd, true, P.sigma, P.mode);
-      const float* fu = face_uv_row(P, n, fid);
-      const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
-      const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
-      const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
-      int onw, one, osw, ose;
-      bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
-      float tex[4][3], col[3];
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        tex[0][ch] = map[onw + ch];
-        tex[1][ch] = one >= 0 ? map[one + ch] : 0.0f;
-        tex[2][ch] = osw >= 0 ? map[osw + ch] : 0.0f;
-        tex[3][ch] = ose >= 0 ? map[ose + ch] : 0.0f;
-        float acc = 0.0f;
-        acc += tex[0][ch] * bl.wnw; acc += tex[1][ch] * bl.wne; acc += tex[2][ch] * bl.wsw; acc += tex[3][ch] * bl.wse;
-        col[ch] = P.use_amb ? acc * P.amb[ch] : acc;
-      }
-      const float cg = g0 * col[0] + g1 * col[1] + g2 * col[2];
-      const float ga = occ * (cg - behind) + g3 * occ * trans;
       const float gd = ga * layer_dalpha(ev.sd, a, true, P.sigma, P.mode);
-      const float wgt = occ * a;
       float o[6] = {0, 0, 0, 0, 0, 0};
       if (wgt != 0.0f) {
-        float gc[3] = {wgt * g0, wgt * g1, wgt * g2};
+        const float* fu = face_uv_row(P, n, fid);
+        const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
+        const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
+        const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+        int onw, one, osw, ose;
+        bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
+        float gc[3] = {wgt * q0, wgt * q1, wgt * q2};
         if (P.use_amb) { gc[0] *= P.amb[0]; gc[1] *= P.amb[1]; gc[2] *= P.amb[2]; }
-        float gix = 0.0f, giy = 0.0f;
-        const float y1 = (float)(bl.y0 + 1), x1 = (float)(bl.x0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
+        if (P.gfv) {
+          float gix = 0.0f, giy = 0.0f;
+          const float y1 = (float)(bl.y0 + 1), x1 = (float)(bl.x0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float g = gc[ch];
-          gix -= tex[0][ch] * (y1 - bl.iy) * g; giy -= tex[0][ch] * (x1 - bl.ix) * g;
-          gix += tex[1][ch] * (y1 - bl.iy) * g; giy -= tex[1][ch] * (bl.ix - x0) * g;
-          gix -= tex[2][ch] * (bl.iy - y0) * g; giy += tex[2][ch] * (x1 - bl.ix) * g;
-          gix += tex[3][ch] * (bl.iy - y0) * g; giy += tex[3][ch] * (bl.ix - x0) * g;
+          for (int ch = 0; ch < 3; ++ch) {
+            const float t0 = map[onw + ch], t1 = one >= 0 ? map[one + ch] : 0.0f;
+            const float t2 = osw >= 0 ? map[osw + ch] : 0.0f, t3 = ose >= 0 ? map[ose + ch] : 0.0f;
+            const float g = gc[ch];
+            gix -= t0 * (y1 - bl.iy) * g; giy -= t0 * (x1 - bl.ix) * g;
+            gix += t1 * (y1 - bl.iy) * g; giy -= t1 * (bl.ix - x0) * g;
+            gix -= t2 * (bl.iy - y0) * g; giy += t2 * (x1 - bl.ix) * g;
+            gix += t3 * (bl.iy - y0) * g; giy += t3 * (bl.ix - x0) * g;
+          }
+          const float gu = gix * bl.mx * 2.0f, gv = giy * bl.my * 2.0f;
+          const float gb0 = gu * fu[0] + gv * fu[1], gb1 = gu * fu[2] + gv * fu[3], gb2 = gu * fu[4] + gv * fu[5];
+          bary_path_bwd(fc, ev, px, py, clip, gb0, gb1, gb2, o);
         }
         if (gmap) {
           const int offs[4] = {onw, one, osw, ose};
@@ -741,11 +933,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
               for (int ch = 0; ch < 3; ++ch) atomicAdd(gmap + offs[q] + ch, gc[ch] * wts[q]);
             }
           }
-        }
-        if (P.gfv) {
-          const float gu = gix * bl.mx * 2.0f, gv = giy * bl.my * 2.0f;
-          const float gb0 = gu * fu[0] + gv * fu[1], gb1 = gu * fu[2] + gv * fu[3], gb2 = gu * fu[4] + gv * fu[5];
-          bary_path_bwd(fc, ev, px, py, clip, gb0, gb1, gb2, o);
         }
       }
       if (P.gfv && gd != 0.0f) {
@@ -771,8 +958,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
             if (o[i] != 0.0f) atomicAdd(gf + (i >> 1) * 3 + (i & 1), o[i]);
         }
       }
-      behind = a * cg + (1.0f - a) * behind;
-      trans = trans * (1.0f - a);
     }
   }
 
@@ -1052,9 +1237,10 @@ const char* ur_last_error(void) { return g_err; }
 int ur_abi_version(void) { return 1; }
 
 size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
-  // bbox (16 B) + record (80 B) per face, then the spill area of the per-pixel K-lists (only when K exceeds what
+  // bbox (16 B) + record (80 B) + nearest depth (4 B) per face, then the spill area of the per-pixel K-lists (only when K exceeds what
   // LDS holds)
-  return (size_t)(total_faces < 1 ? 1 : total_faces) * 96 + raster_spill_bytes(N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
+  const size_t nf = (size_t)(total_faces < 1 ? 1 : total_faces);
+  return nf * 96 + ((nf + 3) / 4) * 16 + raster_spill_bytes(N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
 }
 
 int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
@@ -1172,8 +1358,12 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
   return check_launch("k_shade_bwd");
 }
 
+size_t ur_backward_scratch_bytes(int N, int H, int W, int K) {
+  return (size_t)(N < 0 ? 0 : N) * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)K * 64 * 2 * 4;
+}
+
 size_t ur_layers_elems(int N, int H, int W, int K) {
-  return (size_t)(N < 0 ? 0 : N) * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)K * 64 * 2;
+  return (size_t)(N < 0 ? 0 : N) * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)K * 64 * 6;
 }
 
 static int fill_render_params(RasterParams& P, const int64_t* first, const int64_t* nfaces, int N, int H, int W,
@@ -1216,9 +1406,10 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
                                float blur_radius, int K, int clip_barycentric_coords, const float* maps,
                                const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
                                const float* background, const float* ambient, int mode, const int32_t* layers,
-                               const void* workspace, size_t workspace_bytes, float* grad_face_verts,
-                               float* grad_maps, void* stream) {
-  if (!grad_image || !layers || !workspace) return fail(UR_ERR_INVALID_ARG, "null pointer");
+                               const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                               float* grad_face_verts, float* grad_maps, void* stream) {
+  if (!grad_image || !layers || !workspace || !scratch) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (scratch_bytes < ur_backward_scratch_bytes(N, H, W, K)) return fail(UR_ERR_WORKSPACE, "scratch too small");
   if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
   if (workspace_bytes < ur_workspace_bytes(total_faces, 0, H, W, K)) return fail(UR_ERR_WORKSPACE, "workspace too small");
   RasterParams P{};
@@ -1230,6 +1421,7 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   P.rec = P.bbox + total_faces;
   P.layers = const_cast<int32_t*>(layers);
   P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
+  P.scratch = reinterpret_cast<float*>(scratch);
   P.nbx = (W + 15) / 16;
   P.nby = (H + 15) / 16;
   const int64_t blocks = (int64_t)N * P.nbx * P.nby;

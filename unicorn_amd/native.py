@@ -32,8 +32,9 @@ _SIGNATURES = {
     "ur_layers_elems": (_sz, [_i, _i, _i, _i]),
     "ur_render_layered_forward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
                                        _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ur_backward_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ur_render_layered_backward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
-                                        _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
+                                        _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "ur_shade_blend_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i,
                                      _vp, _vp, _vp, _vp]),
 }
@@ -295,12 +296,14 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
     dev = maps.device
     gfv = torch.zeros(total_faces, 3, 3, dtype=torch.float32, device=dev) if need_face_verts else None
     gmaps = torch.zeros_like(maps) if need_maps else None
+    scratch = torch.empty(int(lib().ur_backward_scratch_bytes(N, H, W, K)), dtype=torch.uint8, device=dev)
     with _on(maps), _timed("ur_render_layered_backward", maps):
         _check(lib().ur_render_layered_backward(
             _ptr(grad_image, torch.float32), _ptr(mesh_first_face, torch.int64), _ptr(mesh_num_faces, torch.int64), N,
             int(total_faces), H, W, float(blur_radius), K, int(clip_barycentric_coords), _ptr(maps, torch.float32),
             _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt, float(sigma),
             ctypes.cast(_rgb(background), _vp), ctypes.cast(_rgb(ambient), _vp) if ambient is not None else None,
-            int(mode), _ptr(layers, torch.int32), _ptr(workspace), workspace.numel(), _ptr(gfv, None, True),
+            int(mode), _ptr(layers, torch.int32), _ptr(workspace), workspace.numel(), _ptr(scratch), scratch.numel(),
+            _ptr(gfv, None, True),
             _ptr(gmaps, None, True), _stream(maps)), "ur_render_layered_backward")
     return gfv, gmaps
