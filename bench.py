@@ -17,11 +17,11 @@ import time
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from unicorn_amd import dist as udist  # noqa: E402
 from unicorn_amd import native, synth  # noqa: E402
 from unicorn_amd.renderer import Renderer  # noqa: E402
 from unicorn_amd.structures import Meshes, TexturesUV  # noqa: E402
@@ -92,19 +92,16 @@ def main():
                     "reported metric uses the default = all of them)")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    rank, local, world = udist.env_world()
     torch.cuda.set_device(local)
+    udist.init("nccl")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
     native.lib()
 
     cfg = WORKLOADS[a.workload]
     B, H, K = cfg["B"], cfg["img"], cfg["K"]
-    sc = synth.make_scene(B, level=cfg["level"], tex_size=cfg["tex"], seed=100 * rank, device=dev)
+    sc = synth.make_scene(B, level=cfg["level"], tex_size=cfg["tex"], seed=udist.shard_seed(0, rank), device=dev)
     F = sc["faces"].shape[0]
     rend = Renderer(H, cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=1e-4).to(dev)
     want = set(a.grads.split("+"))
@@ -123,24 +120,7 @@ def main():
         img.backward(cot)
         return img
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = udist.timed_steps(step, a.steps, a.warmup, world, cuda=True)
 
     # roofline leg: the same steps again with HIP events around every C-ABI call (rank 0 only)
     result = None
@@ -151,10 +131,16 @@ def main():
         per_call = native.timing_summary()
         native.enable_timing(False)
         dom = max(per_call, key=lambda k: per_call[k][1])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):  # PMC counters cannot be read from inside the process: last committed measurement
+            tj = json.load(open(tpath))
+            if tj.get("workload") == a.workload and dom in tj:
+                traffic = int((2 * tj[dom]["FETCH_SIZE"] + tj[dom]["WRITE_SIZE"]) * 1024)
         raster_ms = per_call[dom][1]
         alg = B * kernel_bytes_per_image(dom, H, H, K, F, cfg["tex"], cfg["tex"])
         achieved = alg / (raster_ms * 1e-3) / 1e9
-        ips = world * B * a.steps / elapsed
+        ips = udist.job_throughput(B, a.steps, elapsed, world)
         path_gbps = ips / world * path_bytes_per_image(H, H, K, F, cfg["tex"], cfg["tex"]) / 1e9
         result = {
             "metric": "rendered images/sec fwd+bwd (B=32, 128x128, K=50)", "value": round(ips, 2),
@@ -166,7 +152,7 @@ def main():
                        "grads": a.grads},
             "roofline": {"bound": "hbm", "kernel": {"ur_render_layered_forward": "k_raster<4,2>", "ur_render_layered_backward": "k_render_bwd"}.get(dom, dom), "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "algorithmic_bytes_per_launch": alg,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg,
                          "kernel_ms": round(raster_ms, 4), "dominant_call": dom,
                          "note": "algorithmic bytes = this launch's share of SURVEY 8(d) (fragments counted as if "
                                  "materialised); the fused kernels keep fragments on chip, so real HBM traffic is "
@@ -179,9 +165,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(cfg)
             result["gpu_over_cpu"] = round(ips / result["cpu_baseline"]["value"], 1)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    udist.finish(world)
     if rank == 0:
         print(json.dumps(result))
 

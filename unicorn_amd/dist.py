@@ -1,0 +1,70 @@
+"""Data-parallel plumbing of the render benchmark / a DDP training step: one process per GPU, launched by
+`torch.distributed.run` (reference: mp.spawn + NCCL DDP, trainer.py:260-264,284-290).  The renderer itself needs no
+collective -- images are independent units, each rank renders its own shard of the batch -- so the only
+communication here is the barrier / max-reduce that brackets a timed region."""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None):
+    """-> (rank, local_rank, world).  backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU."""
+    rank, local, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+    return rank, local, world
+
+
+def shard_seed(base_seed, rank):
+    """every rank draws its own synthetic shard (the reference seeds with seed + rank, trainer.py:263)"""
+    return base_seed + 100 * rank
+
+
+def fence(world, cuda):
+    if cuda:
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize()
+
+
+def timed_steps(step, steps, warmup, world, cuda):
+    """warmup untimed steps, then exactly `steps` timed ones between two fences; returns the MAX over ranks of the
+    elapsed seconds (identical on every rank)."""
+    for _ in range(warmup):
+        step()
+    fence(world, cuda)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence(world, cuda)
+    return max_over_ranks(time.perf_counter() - t0, world, cuda)
+
+
+def max_over_ranks(value, world, cuda):
+    if world == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_throughput(units_per_rank, steps, elapsed_max, world):
+    """whole-job units/s: every rank processed units_per_rank * steps units in (at most) elapsed_max seconds"""
+    return world * units_per_rank * steps / elapsed_max
+
+
+def finish(world):
+    if world > 1 and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
