@@ -1210,6 +1210,71 @@ __global__ void __launch_bounds__(256) k_project_faces_bwd(const float* __restri
   }
 }
 
+// One workgroup per mesh: per-corner gradients are first summed per VERTEX in LDS (the projection is linear in the
+// upstream gradient and depends on the vertex only), then every vertex is pushed through the camera once; the R / T
+// sums are reduced in the workgroup.  No global atomics; outputs are plainly stored.
+__global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __restrict__ verts,
+                                                                 const int64_t* __restrict__ faces, int64_t fstride,
+                                                                 const float* __restrict__ R,
+                                                                 const float* __restrict__ T, float sx, float sy,
+                                                                 int V, int F, const float* __restrict__ gfv,
+                                                                 float* __restrict__ gverts, float* __restrict__ gR,
+                                                                 float* __restrict__ gT) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* acc = reinterpret_cast<float*>(smem);  // V*3, then 16*12 partial sums
+  float* part = acc + (size_t)V * 3;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < V * 3; i += 1024) acc[i] = 0.0f;
+  __syncthreads();
+  const int64_t* fc = faces + (int64_t)n * fstride;
+  const float* g = gfv + (int64_t)n * F * 9;
+  for (int c = tid; c < F * 3; c += 1024) {
+    const int vi = (int)fc[c];
+    atomicAdd(&acc[vi * 3 + 0], g[c * 3 + 0]);
+    atomicAdd(&acc[vi * 3 + 1], g[c * 3 + 1]);
+    atomicAdd(&acc[vi * 3 + 2], g[c * 3 + 2]);
+  }
+  __syncthreads();
+  const float* r = R + (int64_t)n * 9;
+  const float* t = T + (int64_t)n * 3;
+  float s[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) s[q] = 0.0f;
+  for (int v = tid; v < V; v += 1024) {
+    const float* p = verts + ((int64_t)n * V + v) * 3;
+    const float g0 = acc[v * 3 + 0], g1 = acc[v * 3 + 1], g2 = acc[v * 3 + 2];
+    const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
+    const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
+    const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
+    const float gv[3] = {g0 * sx / vz, g1 * sy / vz, g2 - (g0 * sx * vx + g1 * sy * vy) / (vz * vz)};
+    if (gverts) {
+      float* go = gverts + ((int64_t)n * V + v) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) go[i] = gv[0] * r[i * 3 + 0] + gv[1] * r[i * 3 + 1] + gv[2] * r[i * 3 + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s[i * 3 + j] += p[i] * gv[j];
+    s[9] += gv[0]; s[10] += gv[1]; s[11] += gv[2];
+  }
+  if (!gR && !gT) return;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    float v = s[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((tid & 63) == 0) part[(tid >> 6) * 12 + q] = v;
+  }
+  __syncthreads();
+  if (tid < 12) {
+    float v = 0.0f;
+    for (int w = 0; w < 16; ++w) v += part[w * 12 + tid];
+    if (tid < 9) { if (gR) gR[(int64_t)n * 9 + tid] = v; }
+    else if (gT) gT[(int64_t)n * 3 + tid - 9] = v;
+  }
+}
+
 int fill_shade_params(ShadeParams& P, const int32_t* p2f, const float* bary, const float* dists, const float* maps,
                       const float* fuv, int fuv_shared, const int64_t* first, int N, int H, int W, int K, int Ht, int Wt,
                       float sigma, const float* bg, const float* amb, int mode) {
@@ -1260,7 +1325,24 @@ int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t 
   if (!verts || !faces || !R || !T || !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
   if (N == 0 || F == 0 || (!grad_verts && !grad_R && !grad_T)) return UR_OK;
+  const size_t lds = ((size_t)V * 3 + 16 * 12) * 4;
+  if (lds <= 150 * 1024) {
+    static thread_local size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_faces_bwd_mesh),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      configured = lds;
+    }
+    hipLaunchKernelGGL(k_project_faces_bwd_mesh, dim3((unsigned)N), dim3(1024), lds, (hipStream_t)stream, verts, faces,
+                       faces_mesh_stride, R, T, sx, sy, V, F, grad_face_verts, grad_verts, grad_R, grad_T);
+    return check_launch("k_project_faces_bwd_mesh");
+  }
   if (N > 65535) return fail(UR_ERR_INVALID_ARG, "N > 65535 meshes per call");
+  // very large meshes: float atomics into zeroed outputs
+  if (grad_verts) hipMemsetAsync(grad_verts, 0, (size_t)N * V * 12, (hipStream_t)stream);
+  if (grad_R) hipMemsetAsync(grad_R, 0, (size_t)N * 36, (hipStream_t)stream);
+  if (grad_T) hipMemsetAsync(grad_T, 0, (size_t)N * 12, (hipStream_t)stream);
   hipLaunchKernelGGL(k_project_faces_bwd, dim3((unsigned)((F * 3 + 255) / 256), (unsigned)N), dim3(256), 0,
                      (hipStream_t)stream, verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts,
                      grad_verts, grad_R, grad_T);

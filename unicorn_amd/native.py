@@ -158,9 +158,9 @@ def project_faces(verts, faces, R, T, sx, sy):
 def project_faces_backward(verts, faces, R, T, sx, sy, grad_face_verts, need_verts=True, need_R=True, need_T=True):
     N, V = verts.shape[:2]
     F, fstride = _faces_layout(faces, N)
-    gv = torch.zeros_like(verts) if need_verts else None
-    gR = torch.zeros_like(R) if need_R else None
-    gT = torch.zeros_like(T) if need_T else None
+    gv = torch.empty_like(verts) if need_verts else None
+    gR = torch.empty_like(R) if need_R else None
+    gT = torch.empty_like(T) if need_T else None
     with _on(verts), _timed("ur_project_faces_backward", verts):
         _check(lib().ur_project_faces_backward(_ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
                                                _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F,
