@@ -132,6 +132,11 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
  *   grad_face_verts (NF,3,3) and grad_maps (N,Ht,Wt,3) must be zero-filled by the caller; either may be NULL
  *   (then that gradient is skipped).  The z column of grad_face_verts stays 0 (the layered blend never reads zbuf).
  */
+/* Self-test (no counterpart in the reference): the kernels divide by per-face quantities through a 5-instruction
+ * exact-division sequence; this compares it with the hardware's IEEE division on n pseudo-random operand pairs and
+ * adds the number of mismatching quotients to *mismatches (device uint64, zeroed by the caller).  Expected: 0. */
+int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* stream);
+
 size_t ur_layers_elems(int N, int H, int W, int K);
 size_t ur_backward_scratch_bytes(int N, int H, int W, int K);
 

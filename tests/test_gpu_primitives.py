@@ -215,3 +215,9 @@ def test_error_reporting(native):
         native.rasterize_meshes(fv, one, one + 1, (8, 8), 0.0, 0, False)
     with pytest.raises(ValueError, match="GPU"):
         native.rasterize_meshes(fv.cpu(), one, one + 1, (8, 8), 0.0, 1, False)
+
+
+def test_exact_division_sequence(native):
+    """the 5-instruction a/b = f(a, b, RN(1/b)) used per (pixel, face) must equal IEEE division bit for bit"""
+    assert native.selftest_division(1 << 30, seed=1) == 0
+    assert native.selftest_division(1 << 28, seed=12345) == 0

@@ -23,38 +23,55 @@ __device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) {
   return -offset + (range * (float)i + offset) / (float)S1;
 }
 
+// Correctly rounded a / b from y = RN(1 / b) (computed once per face with an IEEE division): two Newton steps on the
+// quotient with exact fma residuals.  q0 = RN(a y) is within 2 ulp; the first step makes it faithful, and for a
+// faithful q with y = RN(1/b) Markstein's theorem gives RN(a/b) after the second.  Five instructions instead of the
+// ~10 of the full IEEE sequence; the only observable difference is the sign of a zero quotient.  Checked against
+// `/` bit for bit by ur_selftest_division and, on whole scenes, by every bit-exact parity test.
+__device__ __forceinline__ float div_by(float a, float b, float y) {
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+
 // Per-face record prepared once per call (k_face_prep): everything that does not depend on the pixel.
 //   rec[5*f+0] = v0x v0y v1x v1y
 //   rec[5*f+1] = v2x v2y z0  z1
-//   rec[5*f+2] = z2  denom l2(v0v1) l2(v0v2)          denom = edge(v2; v0, v1) + 1e-8
-//   rec[5*f+3] = l2(v1v2) d01x d01y d12x              dab = vb - va
-//   rec[5*f+4] = d12y d20x d20y 0
+//   rec[5*f+2] = z2  denom 1/denom l2(v0v1)           denom = edge(v2; v0, v1) + 1e-8 ; reciprocals are RN(1/x)
+//   rec[5*f+3] = l2(v0v2) l2(v1v2) 1/l2(v0v1) 1/l2(v0v2)
+//   rec[5*f+4] = 1/l2(v1v2) d12x d12y zmin            d12 = v2 - v1 ; zmin = nearest corner depth
 //   bbox[f]    = xlo xhi ylo yhi                      blur-expanded; culled faces get xlo = +inf, xhi = -inf
 struct Face {
-  float v0x, v0y, v1x, v1y, v2x, v2y, z0, z1, z2, denom, l01, l02, l12, d01x, d01y, d12x, d12y, d20x, d20y;
+  float v0x, v0y, v1x, v1y, v2x, v2y, z0, z1, z2, denom, idenom, l01, l02, l12, il01, il02, il12, d12x, d12y, zmin;
 };
 
-__device__ __forceinline__ Face load_face(const float4* __restrict__ rec, int fid) {
-  const float4 a = rec[5 * (size_t)fid + 0], b = rec[5 * (size_t)fid + 1], c = rec[5 * (size_t)fid + 2],
-               d = rec[5 * (size_t)fid + 3], e = rec[5 * (size_t)fid + 4];
+__device__ __forceinline__ Face unpack_face(const float4 a, const float4 b, const float4 c, const float4 d,
+                                            const float4 e) {
   Face f;
   f.v0x = a.x; f.v0y = a.y; f.v1x = a.z; f.v1y = a.w;
   f.v2x = b.x; f.v2y = b.y; f.z0 = b.z; f.z1 = b.w;
-  f.z2 = c.x; f.denom = c.y; f.l01 = c.z; f.l02 = c.w;
-  f.l12 = d.x; f.d01x = d.y; f.d01y = d.z; f.d12x = d.w;
-  f.d12y = e.x; f.d20x = e.y; f.d20y = e.z;
+  f.z2 = c.x; f.denom = c.y; f.idenom = c.z; f.l01 = c.w;
+  f.l02 = d.x; f.l12 = d.y; f.il01 = d.z; f.il02 = d.w;
+  f.il12 = e.x; f.d12x = e.y; f.d12y = e.z; f.zmin = e.w;
   return f;
 }
 
-// squared distance from p to segment a-b ; (bax, bay) = b - a and l2 = |b - a|^2 come from the record
+__device__ __forceinline__ Face load_face(const float4* __restrict__ rec, int fid) {
+  return unpack_face(rec[5 * (size_t)fid + 0], rec[5 * (size_t)fid + 1], rec[5 * (size_t)fid + 2],
+                     rec[5 * (size_t)fid + 3], rec[5 * (size_t)fid + 4]);
+}
+
+// squared distance from p to segment a-b ; (bax, bay) = b - a, l2 = |b - a|^2 and il2 = RN(1/l2)
 __device__ __forceinline__ float seg_dist(float px, float py, float ax, float ay, float bx, float by, float bax,
-                                          float bay, float l2) {
+                                          float bay, float l2, float il2) {
   if (l2 <= kEps) {
     const float dx = px - bx, dy = py - by;
     return dx * dx + dy * dy;
   }
   const float pax = px - ax, pay = py - ay;
-  const float t = (bax * pax + bay * pay) / l2;
+  const float t = div_by(bax * pax + bay * pay, l2, il2);
   const float tt = min_s(max_s(t, 0.0f), 1.0f);
   const float qx = ax + tt * bax, qy = ay + tt * bay;
   const float dx = px - qx, dy = py - qy;
@@ -71,10 +88,11 @@ struct Eval {
 // The (pixel, face) test.  Returns false when the face does not contribute to the pixel.  The bbox test against the
 // blur-expanded box must have been done by the caller (it needs the bbox, not the record).
 __device__ __forceinline__ bool eval_face(const Face& f, float px, float py, float blur, bool clip, Eval& o) {
+  const float d01x = f.v1x - f.v0x, d01y = f.v1y - f.v0y, d20x = f.v0x - f.v2x, d20y = f.v0y - f.v2y;
   const float e0 = (px - f.v1x) * f.d12y - (py - f.v1y) * f.d12x;  // edge(p; v1, v2)
-  const float e1 = (px - f.v2x) * f.d20y - (py - f.v2y) * f.d20x;  // edge(p; v2, v0)
-  const float e2 = (px - f.v0x) * f.d01y - (py - f.v0y) * f.d01x;  // edge(p; v0, v1)
-  o.w0 = e0 / f.denom; o.w1 = e1 / f.denom; o.w2 = e2 / f.denom;
+  const float e1 = (px - f.v2x) * d20y - (py - f.v2y) * d20x;      // edge(p; v2, v0)
+  const float e2 = (px - f.v0x) * d01y - (py - f.v0y) * d01x;      // edge(p; v0, v1)
+  o.w0 = div_by(e0, f.denom, f.idenom); o.w1 = div_by(e1, f.denom, f.idenom); o.w2 = div_by(e2, f.denom, f.idenom);
   float c0 = o.w0, c1 = o.w1, c2 = o.w2;
   if (clip) {
     c0 = max_s(c0, 0.0f); c1 = max_s(c1, 0.0f); c2 = max_s(c2, 0.0f);
@@ -84,9 +102,9 @@ __device__ __forceinline__ bool eval_face(const Face& f, float px, float py, flo
   float pz = c0 * f.z0 + c1 * f.z1 + c2 * f.z2;
   if (pz < 0.0f) return false;
   pz = pz + 0.0f;  // -0 -> +0: depth keys are compared as unsigned bit patterns
-  o.d01 = seg_dist(px, py, f.v0x, f.v0y, f.v1x, f.v1y, f.d01x, f.d01y, f.l01);
-  o.d02 = seg_dist(px, py, f.v0x, f.v0y, f.v2x, f.v2y, -f.d20x, -f.d20y, f.l02);
-  o.d12 = seg_dist(px, py, f.v1x, f.v1y, f.v2x, f.v2y, f.d12x, f.d12y, f.l12);
+  o.d01 = seg_dist(px, py, f.v0x, f.v0y, f.v1x, f.v1y, d01x, d01y, f.l01, f.il01);
+  o.d02 = seg_dist(px, py, f.v0x, f.v0y, f.v2x, f.v2y, -d20x, -d20y, f.l02, f.il02);
+  o.d12 = seg_dist(px, py, f.v1x, f.v1y, f.v2x, f.v2y, f.d12x, f.d12y, f.l12, f.il12);
   const float dist = min_s(min_s(o.d01, o.d02), o.d12);
   o.inside = (o.w0 > 0.0f) && (o.w1 > 0.0f) && (o.w2 > 0.0f);
   if (!o.inside && dist >= blur) return false;

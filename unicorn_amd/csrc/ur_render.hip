@@ -61,14 +61,14 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
   bbox[i] = make_float4(xlo, xhi, ylo, yhi);
   fz[i] = min_s(min_s(z0, z1), z2);
   const float denom = ((v2x - v0x) * (v1y - v0y) - (v2y - v0y) * (v1x - v0x)) + kEps;  // edge(v2; v0, v1) + eps
-  const float d01x = v1x - v0x, d01y = v1y - v0y, d12x = v2x - v1x, d12y = v2y - v1y, d20x = v0x - v2x,
-              d20y = v0y - v2y;
+  const float d01x = v1x - v0x, d01y = v1y - v0y, d12x = v2x - v1x, d12y = v2y - v1y;
   const float d02x = v2x - v0x, d02y = v2y - v0y;
+  const float l01 = d01x * d01x + d01y * d01y, l02 = d02x * d02x + d02y * d02y, l12 = d12x * d12x + d12y * d12y;
   rec[5 * i + 0] = make_float4(v0x, v0y, v1x, v1y);
   rec[5 * i + 1] = make_float4(v2x, v2y, z0, z1);
-  rec[5 * i + 2] = make_float4(z2, denom, d01x * d01x + d01y * d01y, d02x * d02x + d02y * d02y);
-  rec[5 * i + 3] = make_float4(d12x * d12x + d12y * d12y, d01x, d01y, d12x);
-  rec[5 * i + 4] = make_float4(d12y, d20x, d20y, 0.0f);
+  rec[5 * i + 2] = make_float4(z2, denom, 1.0f / denom, l01);
+  rec[5 * i + 3] = make_float4(l02, l12, 1.0f / l01, 1.0f / l02);
+  rec[5 * i + 4] = make_float4(1.0f / l12, d12x, d12y, min_s(min_s(z0, z1), z2));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -136,17 +136,6 @@ __device__ __forceinline__ int wave_max(int v) {
 __device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float xc_hi, float yc_lo, float yc_hi) {
   // bb = xlo xhi ylo yhi ; reject iff the whole centre interval is on one side of the box
   return !(xc_hi < bb.x || xc_lo > bb.y || yc_hi < bb.z || yc_lo > bb.w);
-}
-
-__device__ __forceinline__ Face unpack_face(const float4 a, const float4 b, const float4 c, const float4 d,
-                                            const float4 e) {
-  Face f;
-  f.v0x = a.x; f.v0y = a.y; f.v1x = a.z; f.v1y = a.w;
-  f.v2x = b.x; f.v2y = b.y; f.z0 = b.z; f.z1 = b.w;
-  f.z2 = c.x; f.denom = c.y; f.l01 = c.z; f.l02 = c.w;
-  f.l12 = d.x; f.d01x = d.y; f.d01y = d.z; f.d12x = d.w;
-  f.d12y = e.x; f.d20x = e.y; f.d20y = e.z;
-  return f;
 }
 
 // A key packs (depth bits, face index, hides-the-rest flag): unsigned order == (depth, face) order (depths are >= +0).
@@ -349,7 +338,7 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
             const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
                                         rcs[src * 5 + 4]);
             bool hit = pix_live && !(px < ubb.x || px > ubb.y || py < ubb.z || py > ubb.w);
-            if (can_cull) hit = hit && !(min_s(min_s(fc.z0, fc.z1), fc.z2) * 0.9999f > z_hide);
+            if (can_cull) hit = hit && !(fc.zmin * 0.9999f > z_hide);
             Eval ev;
             if (P.dbg == 3) hit = false;
             if (hit) hit = eval_face(fc, px, py, P.blur, P.clip != 0, ev);
@@ -701,12 +690,12 @@ __device__ __forceinline__ void fragment_bwd(const float* __restrict__ fv, float
   a2y += -gden * (v1x - v0x);
   const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
   const float gd = inside ? -gdist : gdist;
-  const float d01 = seg_dist(px, py, v0x, v0y, v1x, v1y, v1x - v0x, v1y - v0y,
-                             (v1x - v0x) * (v1x - v0x) + (v1y - v0y) * (v1y - v0y));
-  const float d02 = seg_dist(px, py, v0x, v0y, v2x, v2y, v2x - v0x, v2y - v0y,
-                             (v2x - v0x) * (v2x - v0x) + (v2y - v0y) * (v2y - v0y));
-  const float d12 = seg_dist(px, py, v1x, v1y, v2x, v2y, v2x - v1x, v2y - v1y,
-                             (v2x - v1x) * (v2x - v1x) + (v2y - v1y) * (v2y - v1y));
+  const float l01 = (v1x - v0x) * (v1x - v0x) + (v1y - v0y) * (v1y - v0y);
+  const float l02 = (v2x - v0x) * (v2x - v0x) + (v2y - v0y) * (v2y - v0y);
+  const float l12 = (v2x - v1x) * (v2x - v1x) + (v2y - v1y) * (v2y - v1y);
+  const float d01 = seg_dist(px, py, v0x, v0y, v1x, v1y, v1x - v0x, v1y - v0y, l01, 1.0f / l01);
+  const float d02 = seg_dist(px, py, v0x, v0y, v2x, v2y, v2x - v0x, v2y - v0y, l02, 1.0f / l02);
+  const float d12 = seg_dist(px, py, v1x, v1y, v2x, v2y, v2x - v1x, v2y - v1y, l12, 1.0f / l12);
   if (d01 <= d02 && d01 <= d12) seg_bwd(px, py, v0x, v0y, v1x, v1y, gd, a0x, a0y, a1x, a1y);
   else if (d02 <= d01 && d02 <= d12) seg_bwd(px, py, v0x, v0y, v2x, v2y, gd, a0x, a0y, a2x, a2y);
   else seg_bwd(px, py, v1x, v1y, v2x, v2y, gd, a1x, a1y, a2x, a2y);
@@ -1275,6 +1264,26 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
   }
 }
 
+// div_by() against the hardware's IEEE division on pseudo-random operand pairs spanning the ranges the rasterizer
+// produces (numerators down to 0 and to tiny cancellation residues, denominators from 1e-8 up, both signs)
+__global__ void __launch_bounds__(256) k_selftest_division(unsigned long long n, unsigned seed,
+                                                           unsigned long long* mismatches) {
+  unsigned long long bad = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    const unsigned ua = (unsigned)x, ub = (unsigned)(x >> 32);
+    // exponents: a in 2^[-60, 3), b in 2^[-27, 3); random mantissas and signs; every 64th numerator is 0
+    float a = __uint_as_float((ua & 0x807fffffu) | ((67u + (ua >> 23) % 63u) << 23));
+    const float b = __uint_as_float((ub & 0x807fffffu) | ((100u + (ub >> 23) % 30u) << 23));
+    if ((i & 63) == 0) a = 0.0f;
+    const float want = a / b, got = div_by(a, b, 1.0f / b);
+    if (!(want == got)) ++bad;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
 int fill_shade_params(ShadeParams& P, const int32_t* p2f, const float* bary, const float* dists, const float* maps,
                       const float* fuv, int fuv_shared, const int64_t* first, int N, int H, int W, int K, int Ht, int Wt,
                       float sigma, const float* bg, const float* amb, int mode) {
@@ -1340,9 +1349,9 @@ int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t 
   }
   if (N > 65535) return fail(UR_ERR_INVALID_ARG, "N > 65535 meshes per call");
   // very large meshes: float atomics into zeroed outputs
-  if (grad_verts) hipMemsetAsync(grad_verts, 0, (size_t)N * V * 12, (hipStream_t)stream);
-  if (grad_R) hipMemsetAsync(grad_R, 0, (size_t)N * 36, (hipStream_t)stream);
-  if (grad_T) hipMemsetAsync(grad_T, 0, (size_t)N * 12, (hipStream_t)stream);
+  if (grad_verts) (void)hipMemsetAsync(grad_verts, 0, (size_t)N * V * 12, (hipStream_t)stream);
+  if (grad_R) (void)hipMemsetAsync(grad_R, 0, (size_t)N * 36, (hipStream_t)stream);
+  if (grad_T) (void)hipMemsetAsync(grad_T, 0, (size_t)N * 12, (hipStream_t)stream);
   hipLaunchKernelGGL(k_project_faces_bwd, dim3((unsigned)((F * 3 + 255) / 256), (unsigned)N), dim3(256), 0,
                      (hipStream_t)stream, verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts,
                      grad_verts, grad_R, grad_T);
@@ -1438,6 +1447,13 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
   if (lds > 64 * 1024) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d too large for the blend backward", K);
   hipLaunchKernelGGL(k_shade_bwd, dim3((unsigned)((npix + 63) / 64)), dim3(64), lds, (hipStream_t)stream, P);
   return check_launch("k_shade_bwd");
+}
+
+int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* stream) {
+  if (!mismatches) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  hipLaunchKernelGGL(k_selftest_division, dim3(2048), dim3(256), 0, (hipStream_t)stream, (unsigned long long)n, seed,
+                     reinterpret_cast<unsigned long long*>(mismatches));
+  return check_launch("k_selftest_division");
 }
 
 size_t ur_backward_scratch_bytes(int N, int H, int W, int K) {

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "ur_tile_faces": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ur_shade_blend": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
     "ur_layers_elems": (_sz, [_i, _i, _i, _i]),
+    "ur_selftest_division": (_i, [ctypes.c_uint64, ctypes.c_uint32, _vp, _vp]),
     "ur_render_layered_forward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
                                        _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "ur_backward_scratch_bytes": (_sz, [_i, _i, _i, _i]),
@@ -307,3 +308,12 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
             _ptr(gfv, None, True),
             _ptr(gmaps, None, True), _stream(maps)), "ur_render_layered_backward")
     return gfv, gmaps
+
+
+def selftest_division(n, seed=0, device="cuda"):
+    """number of (a, b) pairs, out of n pseudo-random ones, where the kernels' exact-division sequence differs from
+    the hardware's IEEE division (expected 0)"""
+    out = torch.zeros(1, dtype=torch.int64, device=device)
+    with _on(out):
+        _check(lib().ur_selftest_division(int(n), int(seed), _ptr(out), _stream(out)), "ur_selftest_division")
+    return int(out.item())
