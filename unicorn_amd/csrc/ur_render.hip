@@ -741,12 +741,15 @@ __global__ void __launch_bounds__(256) k_raster_bwd(const float* __restrict__ fv
 // distribution over pixels is.
 //
 // Scatter: instead of one global float atomic per (pixel, layer, component) -- 64 lanes hitting 64 different faces /
-// texture rows, the slowest shape for the memory-side atomic units -- the workgroup first sums in two small LDS
-// tables (ds_add_f32), keyed by face index / texel index, claimed with an LDS compare-and-swap on a tag; a key whose
-// slot is taken by another key falls back to the global atomic.  One flush per workgroup at the end.
+// texture rows, the slowest shape for the memory-side atomic units (~16 G atomics/s measured) -- the workgroup first
+// sums in two small LDS tables keyed by face index / texel index, claimed with an LDS compare-and-swap on a tag; a
+// key whose slot is taken by another key falls back to the global atomic.  One flush per workgroup at the end.
+// The tables hold DOUBLES: gfx950's LDS executes ds_add_f64 at full rate (~10 clk per wave instruction, + ~12 clk per
+// extra lane on the same address) but serialises ds_add_f32 lane by lane (~4 clk per active lane, ~250 clk per wave
+// instruction; tools/micro/lds_atomic*.hip) -- f64 sums are 5x faster here and more accurate.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kFaceSlots = 512;  // x 6 floats
-constexpr int kTexSlots = 256;   // x 3 floats ; slot = 16x16 torus over (texel row, texel column)
+constexpr int kFaceSlots = 512;  // x 6 sums
+constexpr int kTexSlots = 256;   // x 3 sums ; slot = 16x16 torus over (texel row, texel column)
 
 __device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, float px, float py, bool clip, float g0,
                                               float g1, float g2, float o[6]) {
@@ -781,17 +784,11 @@ __device__ __forceinline__ bool lds_claim(int* tags, int h, int key) {
 
 __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   __shared__ int s_ftag[kFaceSlots];
-  __shared__ float s_fval[kFaceSlots * 6];
+  __shared__ double s_fval[kFaceSlots * 6];
   __shared__ int s_ttag[kTexSlots];
-  __shared__ float s_tval[kTexSlots * 3];
+  __shared__ double s_tval[kTexSlots * 3];
   __shared__ int s_pre_all[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
-  for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0f;
-  for (int i = tid; i < kTexSlots; i += 256) s_ttag[i] = -1;
-  for (int i = tid; i < kTexSlots * 3; i += 256) s_tval[i] = 0.0f;
-  __syncthreads();
-
   const int H = P.H, W = P.W, K = P.K;
   const int TW = (W + 7) / 8;
   const int bins_per_img = P.nbx * P.nby;
@@ -818,6 +815,12 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     }
   }
   const int maxm = __builtin_amdgcn_readfirstlane(wave_max(m));
+  if (!__syncthreads_or(maxm > 0) || P.dbg == 6) return;  // nothing rendered in this bin
+  for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
+  for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0;
+  for (int i = tid; i < kTexSlots; i += 256) s_ttag[i] = -1;
+  for (int i = tid; i < kTexSlots * 3; i += 256) s_tval[i] = 0.0;
+  __syncthreads();
 
   if (maxm > 0) {
     const int64_t hw = (int64_t)H * W;
@@ -858,7 +861,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     s_pre[lane] = pre;
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
     const bool clip = P.clip != 0;
-    for (int base = 0; base < total; base += 64) {
+    for (int base = 0; base < (P.dbg == 7 ? 0 : total); base += 64) {
       const int item = base + lane;
       int l = 0;
 #pragma unroll
@@ -916,7 +919,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
             const int h = ((trow & 15) << 4) | (tcol & 15);
             if (lds_claim(s_ttag, h, texel)) {
 #pragma unroll
-              for (int ch = 0; ch < 3; ++ch) atomicAdd(&s_tval[h * 3 + ch], gc[ch] * wts[q]);
+              for (int ch = 0; ch < 3; ++ch) atomicAdd(&s_tval[h * 3 + ch], (double)(gc[ch] * wts[q]));
             } else {
 #pragma unroll
               for (int ch = 0; ch < 3; ++ch) atomicAdd(gmap + offs[q] + ch, gc[ch] * wts[q]);
@@ -939,7 +942,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
         if (lds_claim(s_ftag, h, fid)) {
 #pragma unroll
           for (int i = 0; i < 6; ++i)
-            if (o[i] != 0.0f) atomicAdd(&s_fval[h * 6 + i], o[i]);
+            if (o[i] != 0.0f) atomicAdd(&s_fval[h * 6 + i], (double)o[i]);
         } else {
           float* gf = P.gfv + (int64_t)fid * 9;
 #pragma unroll
@@ -955,14 +958,14 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     for (int i = tid; i < kFaceSlots * 6; i += 256) {
       const int slot = i / 6, c = i - slot * 6;
       const int tag = s_ftag[slot];
-      const float v = s_fval[i];
+      const float v = (float)s_fval[i];
       if (tag >= 0 && v != 0.0f) atomicAdd(P.gfv + (int64_t)tag * 9 + (c >> 1) * 3 + (c & 1), v);
     }
   if (gmap)
     for (int i = tid; i < kTexSlots * 3; i += 256) {
       const int slot = i / 3, c = i - slot * 3;
       const int tag = s_ttag[slot];
-      const float v = s_tval[i];
+      const float v = (float)s_tval[i];
       if (tag >= 0 && v != 0.0f) atomicAdd(gmap + (int64_t)tag * 3 + c, v);
     }
 }
@@ -1210,18 +1213,19 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
                                                                  float* __restrict__ gverts, float* __restrict__ gR,
                                                                  float* __restrict__ gT) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* acc = reinterpret_cast<float*>(smem);  // V*3, then 16*12 partial sums
-  float* part = acc + (size_t)V * 3;
+  // f64 sums: the LDS adds doubles at full rate (ds_add_f64) but serialises ds_add_f32 lane by lane (~4 clk/lane)
+  double* acc = reinterpret_cast<double*>(smem);  // V*3, then 16*12 partial sums
+  float* part = reinterpret_cast<float*>(acc + (size_t)V * 3);
   const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < V * 3; i += 1024) acc[i] = 0.0f;
+  for (int i = tid; i < V * 3; i += 1024) acc[i] = 0.0;
   __syncthreads();
   const int64_t* fc = faces + (int64_t)n * fstride;
   const float* g = gfv + (int64_t)n * F * 9;
   for (int c = tid; c < F * 3; c += 1024) {
     const int vi = (int)fc[c];
-    atomicAdd(&acc[vi * 3 + 0], g[c * 3 + 0]);
-    atomicAdd(&acc[vi * 3 + 1], g[c * 3 + 1]);
-    atomicAdd(&acc[vi * 3 + 2], g[c * 3 + 2]);
+    atomicAdd(&acc[vi * 3 + 0], (double)g[c * 3 + 0]);
+    atomicAdd(&acc[vi * 3 + 1], (double)g[c * 3 + 1]);
+    atomicAdd(&acc[vi * 3 + 2], (double)g[c * 3 + 2]);
   }
   __syncthreads();
   const float* r = R + (int64_t)n * 9;
@@ -1231,7 +1235,7 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
   for (int q = 0; q < 12; ++q) s[q] = 0.0f;
   for (int v = tid; v < V; v += 1024) {
     const float* p = verts + ((int64_t)n * V + v) * 3;
-    const float g0 = acc[v * 3 + 0], g1 = acc[v * 3 + 1], g2 = acc[v * 3 + 2];
+    const float g0 = (float)acc[v * 3 + 0], g1 = (float)acc[v * 3 + 1], g2 = (float)acc[v * 3 + 2];
     const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
     const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
     const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
@@ -1334,7 +1338,7 @@ int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t 
   if (!verts || !faces || !R || !T || !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
   if (N == 0 || F == 0 || (!grad_verts && !grad_R && !grad_T)) return UR_OK;
-  const size_t lds = ((size_t)V * 3 + 16 * 12) * 4;
+  const size_t lds = (size_t)V * 3 * 8 + 16 * 12 * 4;
   if (lds <= 150 * 1024) {
     static thread_local size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
@@ -1520,6 +1524,7 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   P.layers = const_cast<int32_t*>(layers);
   P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
   P.scratch = reinterpret_cast<float*>(scratch);
+  { const char* d = getenv("UR_DEBUG"); P.dbg = d ? atoi(d) : 0; }
   P.nbx = (W + 15) / 16;
   P.nby = (H + 15) / 16;
   const int64_t blocks = (int64_t)N * P.nbx * P.nby;
