@@ -85,7 +85,6 @@ struct RasterParams {
   int clip;
   int nbx, nby;  // bins per row / column
   int cap;       // K-list slots per lane held in LDS
-  int dbg;       // development only (UR_DEBUG env): 1 = skip the per-pixel evaluation, 2 = skip shading
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
   // outputs (fragments)
   int32_t* p2f;
@@ -126,6 +125,7 @@ __device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n
 constexpr int kBinCap = 1024;    // bin-list entries per scan round (256 per wave)
 constexpr int kSub = 64;         // faces staged in LDS per fine step
 constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU
+constexpr int kPreStride = 72;   // ints per wave in the pair-prefix array (65 used)
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -157,14 +157,20 @@ struct KeyList {
 
 // MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
 template <int MODE>
-__global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
+__global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BW = 16, BH = 16, WPB = 4;
-  // LDS carve: [bin list 1024 i32][wave counts 16 i32][item prefix 4x64 i32][staged bbox 2x64 float4]
-  //            [staged records 2x320 float4][keys]
+  // LDS carve (kRasterFixedLds bytes, then the keys):
+  //   [bin list 1024 i32][wave counts 16 i32][per wave: 72 i32 pair prefix (reused as the item prefix of the fused
+  //   tail)][per wave: 64 u32 pair decode info][per wave: 64 i32 list lengths][per wave: 64 u64 hide keys]
+  //   [staged bbox 2x64 float4][staged records 2x320 float4][keys]
   int32_t* s_bin = reinterpret_cast<int32_t*>(smem);
   int32_t* s_wcnt = s_bin + kBinCap;
-  float4* s_bb = reinterpret_cast<float4*>(smem + kBinCap * 4 + 64 + 1024);
+  int32_t* s_fpre_all = s_wcnt + 16;
+  uint32_t* s_finfo_all = reinterpret_cast<uint32_t*>(s_fpre_all + 4 * kPreStride);
+  int32_t* s_cnt_all = reinterpret_cast<int32_t*>(s_finfo_all + 4 * 64);
+  unsigned long long* s_hide_all = reinterpret_cast<unsigned long long*>(s_cnt_all + 4 * 64);
+  float4* s_bb = reinterpret_cast<float4*>(s_hide_all + 4 * 64);
   float4* s_rec = s_bb + 2 * kSub;
   unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(s_rec + 2 * kSub * 5);
 
@@ -207,6 +213,30 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
   unsigned long long hide_key = ~0ull;  // smallest key among the hits that hide the rest
   bool stale = false;                   // hide_key moved since this lane's list was last compacted
   const bool can_cull = (MODE == 2) && (P.clip != 0 || P.blur == 0.0f);
+
+  // MODE 2 evaluates (face, pixel) PAIRS dealt out over the lanes (see the fine step); the per-pixel list length and
+  // hide key then live in LDS, where any lane can reach them with integer atomics.
+  int32_t* s_fpre = s_fpre_all + wave * kPreStride;
+  uint32_t* s_finfo = s_finfo_all + wave * 64;
+  int32_t* s_cnt = s_cnt_all + wave * 64;
+  unsigned long long* s_hide = s_hide_all + wave * 64;
+  unsigned long long* const lds_keys = s_keys_all + (size_t)wave * P.cap * 64;
+  unsigned long long* const spill_keys = P.spill + (tile_live ? tile_id : 0) * (int64_t)(K - P.cap) * 64;
+  unsigned long long last_hk = ~0ull;  // hide key this lane's list was last compacted against
+  bool any_stale = false;              // wave-uniform: some pixel's hide key moved since the last compaction
+  float pxc[8], pyc[8];                // the tile's 8 column / 8 row centres (wave-uniform)
+  unsigned livecols = 0, liverows = 0;
+  if (MODE == 2) {
+    s_cnt[lane] = 0;
+    s_hide[lane] = ~0ull;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pxc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), j));
+      pyc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), j * 8));
+      livecols |= (tx0 + j < W) ? (1u << j) : 0u;
+      liverows |= (ty0 + j < H) ? (1u << j) : 0u;
+    }
+  }
 
   const int64_t f0 = P.first[n];
   const int nf = (int)P.nfaces[n];
@@ -313,65 +343,195 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
     stage_load(0);
     stage_write(0);
     __syncthreads();
+    // one face of the staged chunk against this lane's own pixel (lane = pixel); list state in registers
+    auto lockstep_face = [&](int c, int src, const float4* bbs, const float4* rcs) {
+      const int ufid = s_bin[c * kSub + src];  // wave-uniform
+      const float4 ubb = bbs[src];
+      const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
+                                  rcs[src * 5 + 4]);
+      bool hit = pix_live && !(px < ubb.x || px > ubb.y || py < ubb.z || py > ubb.w);
+      if (can_cull) hit = hit && !(fc.zmin * 0.9999f > z_hide);
+      Eval ev;
+      if (hit) hit = eval_face(fc, px, py, P.blur, P.clip != 0, ev);
+      if (hit) {
+        const bool hides = (MODE == 2) && hides_rest(ev.sd, P.sigma, P.mode);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
+                                       ((unsigned)ufid << 1) | (hides ? 1u : 0u);
+        if (hides && key < hide_key) { z_hide = ev.pz; hide_key = key; stale = true; }
+        if (MODE == 2 && stale && cnt >= P.cap && key <= hide_key) {
+          // about to leave LDS (or full): first throw out what the nearest hiding hit has made irrelevant
+          int j = 0;
+          for (int i = 0; i < cnt; ++i) {
+            const unsigned long long kk = keys.get(i);
+            if (kk <= hide_key) { keys.put(j, kk); ++j; }
+          }
+          cnt = j;
+          stale = false;
+        }
+        if (MODE == 2 && key > hide_key) {
+          // behind a hit that hides the rest: irrelevant to the blend
+        } else if (cnt < K) {
+          keys.put(cnt, key);
+          ++cnt;
+        } else {
+          // list full: replace the current maximum when the newcomer is smaller (rare path)
+          unsigned long long mx = 0;
+          int im = 0;
+          for (int i = 0; i < K; ++i) {
+            const unsigned long long kk = keys.get(i);
+            if (kk > mx) { mx = kk; im = i; }
+          }
+          if (key < mx) keys.put(im, key);
+        }
+      }
+    };
+
     for (int c = 0; c < nsub; ++c) {
       if (c + 1 < nsub) stage_load(c + 1);
       if (tile_live) {
         const int cntc = min(kSub, list_n - c * kSub);
         const float4* bbs = s_bb + (c & 1) * kSub;
         const float4* rcs = s_rec + (c & 1) * kSub * 5;
-        bool pass = false;
-        if (lane < cntc) pass = bbox_overlap(bbs[lane], txc_lo, txc_hi, tyc_lo, tyc_hi);
-        unsigned long long m = __ballot(pass);
+        float4 mybb = make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
+        if (lane < cntc) mybb = bbs[lane];
+        const bool pass = (lane < cntc) && bbox_overlap(mybb, txc_lo, txc_hi, tyc_lo, tyc_hi);
         if (MODE == 1) {
+          const unsigned long long m = __ballot(pass);
           if (pass) {
             const int pos = tl_count + __popcll(m & ((1ull << lane) - 1ull));
             if (pos < P.tl_cap) P.tl_lists[tile_id * P.tl_cap + pos] = s_bin[c * kSub + lane];
           }
           tl_count += __popcll(m);
-        } else {
-          if (P.dbg == 1) m = 0;
+        } else if (MODE == 0) {
+          unsigned long long m = __ballot(pass);
           while (m) {
             const int src = __builtin_ctzll(m);
             m &= m - 1;
-            const int ufid = s_bin[c * kSub + src];  // wave-uniform
-            const float4 ubb = bbs[src];
-            const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
-                                        rcs[src * 5 + 4]);
-            bool hit = pix_live && !(px < ubb.x || px > ubb.y || py < ubb.z || py > ubb.w);
-            if (can_cull) hit = hit && !(fc.zmin * 0.9999f > z_hide);
-            Eval ev;
-            if (P.dbg == 3) hit = false;
-            if (hit) hit = eval_face(fc, px, py, P.blur, P.clip != 0, ev);
-            if (hit) {
-              const bool hides = (MODE == 2) && hides_rest(ev.sd, P.sigma, P.mode);
-              const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
-                                             ((unsigned)ufid << 1) | (hides ? 1u : 0u);
-              if (hides && key < hide_key) { z_hide = ev.pz; hide_key = key; stale = true; }
-              if (MODE == 2 && P.dbg != 5 && stale && cnt >= P.cap && key <= hide_key) {
-                // about to leave LDS (or full): first throw out what the nearest hiding hit has made irrelevant
+            lockstep_face(c, src, bbs, rcs);
+          }
+        } else {
+          // ---- MODE 2: a face of this mesh size covers a third of a tile's pixels, so walking faces with lane =
+          //      pixel leaves two lanes in three idle.  Instead every lane first takes one FACE of the chunk and
+          //      finds the rectangle of tile pixels inside its blur-expanded box (the very comparisons a pixel would
+          //      make, on the tile's 8 column / 8 row centres); the (face, pixel) pairs of all rectangles are then
+          //      numbered by a prefix sum and evaluated 64 at a time, whole faces per batch.  A hit is appended to
+          //      its pixel's list with an LDS integer atomic; list order is irrelevant (sorted by key in the tail).
+          unsigned colm = 0, rowm = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            colm |= !(pxc[j] < mybb.x || pxc[j] > mybb.y) ? (1u << j) : 0u;
+            rowm |= !(pyc[j] < mybb.z || pyc[j] > mybb.w) ? (1u << j) : 0u;
+          }
+          colm &= livecols;
+          rowm &= liverows;
+          const int rw = __popc(colm), rh = __popc(rowm);
+          const int area = pass ? rw * rh : 0;
+          const unsigned long long m = __ballot(area > 0);
+          const int nfp = __popcll(m);
+          if (nfp > 0) {
+            int incl = area;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+              const int t = __shfl_up(incl, off, 64);
+              if (lane >= off) incl += t;
+            }
+            const int total_pairs = __builtin_amdgcn_readlane(incl, 63);
+            if (area > 0) {
+              const int rank = __popcll(m & ((1ull << lane) - 1ull));
+              s_fpre[rank] = incl - area;
+              // decode word: chunk slot, rectangle origin, width and ceil(2^15 / width) (q / width for q < 64)
+              s_finfo[rank] = (unsigned)lane | ((unsigned)(__ffs(colm) - 1) << 6) | ((unsigned)(__ffs(rowm) - 1) << 9) |
+                              ((unsigned)rw << 12) | ((unsigned)((32768 + rw - 1) / rw) << 16);
+            }
+            if (lane + 1 >= nfp) s_fpre[lane + 1] = (lane + 1 == nfp) ? total_pairs : 0x7fffffff;
+            // compacted view: lane r holds the r-th face that has pairs
+            const int cpre = s_fpre[lane], cend = s_fpre[lane + 1];
+            const unsigned cinfo = s_finfo[lane];
+            const int lim = min(P.cap, K);
+            int r0 = 0;
+            while (r0 < nfp) {
+              // how many faces can go the pair way: each adds at most one entry to any pixel's list, and no list
+              // may pass K (there the exact keep-the-K-smallest rule takes over, lane = pixel)
+              int c2 = s_cnt[lane];
+              int cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
+              if (any_stale && cmax + (nfp - r0) > lim) {
+                // compact the lists whose hide key moved: drop what the nearest hiding hit made irrelevant
+                const unsigned long long hk = s_hide[lane];
+                const bool need = (hk != last_hk) && c2 > 0;
+                const int mx = __builtin_amdgcn_readfirstlane(wave_max(need ? c2 : 0));
                 int j = 0;
-                for (int i = 0; i < cnt; ++i) {
-                  const unsigned long long kk = keys.get(i);
-                  if (kk <= hide_key) { keys.put(j, kk); ++j; }
-                }
-                cnt = j;
-                stale = false;
+                for (int i = 0; i < mx; ++i)
+                  if (need && i < c2) {
+                    const unsigned long long kk = keys.get(i);
+                    if (kk <= hk) { keys.put(j, kk); ++j; }
+                  }
+                if (need) { c2 = j; s_cnt[lane] = c2; }
+                last_hk = hk;
+                any_stale = false;
+                cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
               }
-              if (MODE == 2 && key > hide_key) {
-                // behind a hit that hides the rest: irrelevant to the blend
-              } else if (cnt < K) {
-                keys.put(cnt, key);
-                ++cnt;
-              } else {
-                // list full: replace the current maximum when the newcomer is smaller (rare path)
-                unsigned long long mx = 0;
-                int im = 0;
-                for (int i = 0; i < K; ++i) {
-                  const unsigned long long kk = keys.get(i);
-                  if (kk > mx) { mx = kk; im = i; }
-                }
-                if (key < mx) keys.put(im, key);
+              const int room = K - cmax;
+              if (room < min(nfp - r0, 4)) {
+                const int r1 = min(nfp, r0 + 8);
+                cnt = c2;
+                hide_key = s_hide[lane];
+                z_hide = (hide_key == ~0ull) ? __builtin_inff() : __uint_as_float((unsigned)(hide_key >> 32));
+                stale = hide_key != last_hk;
+                for (int r = r0; r < r1; ++r)
+                  lockstep_face(c, __builtin_amdgcn_readlane((int)cinfo, r) & 63, bbs, rcs);
+                s_cnt[lane] = cnt;
+                s_hide[lane] = hide_key;
+                if (!stale) last_hk = hide_key;
+                any_stale = any_stale || __any(stale);
+                r0 = r1;
+                continue;
               }
+              const int r1 = r0 + min(nfp - r0, room);
+              const int pbeg = __builtin_amdgcn_readlane(cpre, r0), pend = __builtin_amdgcn_readlane(cend, r1 - 1);
+              bool improved = false;
+              for (int pb = pbeg; pb < pend; pb += 64) {
+                const int pidx = pb + lane;
+                const bool act = pidx < pend;
+                // the faces this batch touches (a few): pick mine by comparing against their first pair
+                unsigned long long fm = __ballot(lane >= r0 && lane < r1 && cend > pb && cpre < pb + 64);
+                int mypre = 0;
+                unsigned info = 0;
+                while (fm) {
+                  const int i = __builtin_ctzll(fm);
+                  fm &= fm - 1;
+                  const int pi = __builtin_amdgcn_readlane(cpre, i);
+                  const unsigned ii = (unsigned)__builtin_amdgcn_readlane((int)cinfo, i);
+                  if (pidx >= pi) { mypre = pi; info = ii; }
+                }
+                const int q = pidx - mypre;
+                const int w = (int)((info >> 12) & 15u);
+                const int dy = (q * (int)(info >> 16)) >> 15, dx = q - dy * w;
+                const int src = (int)(info & 63u);
+                const int pl = act ? ((((int)((info >> 9) & 7u) + dy) << 3) | ((int)((info >> 6) & 7u) + dx)) : lane;
+                const float qx = __shfl(px, pl, 64), qy = __shfl(py, pl, 64);
+                if (act) {
+                  const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
+                                              rcs[src * 5 + 4]);
+                  unsigned long long hk = s_hide[pl];
+                  bool hit = true;
+                  if (can_cull && hk != ~0ull) hit = !(fc.zmin * 0.9999f > __uint_as_float((unsigned)(hk >> 32)));
+                  Eval ev;
+                  if (hit) hit = eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
+                  if (hit) {
+                    const bool hides = hides_rest(ev.sd, P.sigma, P.mode);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
+                                                   ((unsigned)s_bin[c * kSub + src] << 1) | (hides ? 1u : 0u);
+                    if (hides && key < hk) { atomicMin(&s_hide[pl], key); hk = key; improved = true; }
+                    if (key <= hk) {
+                      const int slot = atomicAdd(&s_cnt[pl], 1);
+                      if (slot < P.cap) lds_keys[(size_t)slot * 64 + pl] = key;
+                      else spill_keys[(size_t)(slot - P.cap) * 64 + pl] = key;
+                    }
+                  }
+                }
+              }
+              any_stale = any_stale || __any(improved);
+              r0 = r1;
             }
           }
         }
@@ -398,8 +558,10 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
     //      the lanes that computed them, in depth order, and composites: the arithmetic and its order are exactly
     //      those of a per-pixel loop, so the image is bit-identical to the two-stage path.
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
-    unsigned long long* lds_base = s_keys_all + (size_t)wave * P.cap * 64;
-    unsigned long long* spill_base = P.spill + tile_id * (int64_t)(K - P.cap) * 64;
+    unsigned long long* lds_base = lds_keys;
+    unsigned long long* spill_base = spill_keys;
+    cnt = s_cnt[lane];
+    hide_key = s_hide[lane];
     int n_rel = cnt;
     if (__any(hide_key != ~0ull && cnt > 0)) {
       const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(hide_key != ~0ull ? cnt : 0));
@@ -411,7 +573,7 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
         }
       if (hide_key != ~0ull) n_rel = j;
     }
-    if (!pix_live || P.dbg == 2) n_rel = 0;
+    if (!pix_live) n_rel = 0;
     constexpr int kDeep = 8;
     {
       // short lists: per-lane selection sort
@@ -453,7 +615,6 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
         }
       }
     }
-    if (P.dbg == 4) n_rel = 0;
     const int m = n_rel;  // layers of this pixel that matter, front to back in slots [0, m)
     int incl = m;
 #pragma unroll
@@ -463,7 +624,7 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
     }
     const int pre = incl - m;
     const int total = __builtin_amdgcn_readlane(incl, 63);
-    int* s_pre = s_wcnt + 16 + wave * 64;
+    int* s_pre = s_fpre_all + wave * kPreStride;
     s_pre[lane] = pre;
     int32_t* lay = P.layers + tile_id * (int64_t)K * 6 * 64 + lane;  // [K][6 words][64 lanes]
     float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
@@ -568,12 +729,12 @@ __global__ void __launch_bounds__(256) k_raster(const RasterParams P) {
   }
 }
 
-constexpr size_t kRasterFixedLds = (size_t)kBinCap * 4 + 64 + 1024 + 2 * kSub * 16 + 2 * kSub * 5 * 16;
+constexpr size_t kRasterFixedLds = (size_t)kBinCap * 4 + 64 + 4 * kPreStride * 4 + 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 8 +
+                                   2 * kSub * 16 + 2 * kSub * 5 * 16;
 
 // K-list slots per lane kept in LDS: all K when they fit two workgroups per CU, else what fits (the rest spills)
 int raster_cap(int K) {
   int fit = (int)((kLdsBudget - kRasterFixedLds) / (4 * 64 * 8));
-  if (const char* e = getenv("UR_CAP")) fit = atoi(e);  // development only
   return K < fit ? K : fit;
 }
 
@@ -586,7 +747,6 @@ template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
   P.cap = (MODE == 1) ? 1 : raster_cap(P.K);
-  { const char* d = getenv("UR_DEBUG"); P.dbg = d ? atoi(d) : 0; }
   const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static thread_local size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
@@ -815,7 +975,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     }
   }
   const int maxm = __builtin_amdgcn_readfirstlane(wave_max(m));
-  if (!__syncthreads_or(maxm > 0) || P.dbg == 6) return;  // nothing rendered in this bin
+  if (!__syncthreads_or(maxm > 0)) return;  // nothing rendered in this bin
   for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
   for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0;
   for (int i = tid; i < kTexSlots; i += 256) s_ttag[i] = -1;
@@ -861,7 +1021,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     s_pre[lane] = pre;
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
     const bool clip = P.clip != 0;
-    for (int base = 0; base < (P.dbg == 7 ? 0 : total); base += 64) {
+    for (int base = 0; base < total; base += 64) {
       const int item = base + lane;
       int l = 0;
 #pragma unroll
@@ -1524,7 +1684,6 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   P.layers = const_cast<int32_t*>(layers);
   P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
   P.scratch = reinterpret_cast<float*>(scratch);
-  { const char* d = getenv("UR_DEBUG"); P.dbg = d ? atoi(d) : 0; }
   P.nbx = (W + 15) / 16;
   P.nby = (H + 15) / 16;
   const int64_t blocks = (int64_t)N * P.nbx * P.nby;
