@@ -85,6 +85,7 @@ struct RasterParams {
   int clip;
   int nbx, nby;  // bins per row / column
   int cap;       // K-list slots per lane held in LDS
+  unsigned long long* tim;  // DEV: per-block timestamps
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
   // outputs (fragments)
   int32_t* p2f;
@@ -122,10 +123,17 @@ __device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n
   return P.fuv + fl * 6;
 }
 
-constexpr int kBinCap = 1024;    // bin-list entries per scan round (256 per wave)
+constexpr int kScanQ = 8;         // faces per lane per scan round
+constexpr int kBinCap = 256 * kScanQ;  // faces per scan round = bin-list entries (u16 offsets into the round)
 constexpr int kSub = 64;         // faces staged in LDS per fine step
 constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU
 constexpr int kPreStride = 72;   // ints per wave in the pair-prefix array (65 used)
+
+// r-th index of 0..n-1 counted from the centre outwards: c, c-1, c+1, c-2, ...
+__device__ __forceinline__ int centre_out(int r, int n) {
+  const int c = n >> 1, d = (r + 1) >> 1;
+  return (r & 1) ? c - d : c + d;
+}
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -161,11 +169,11 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BW = 16, BH = 16, WPB = 4;
   // LDS carve (kRasterFixedLds bytes, then the keys):
-  //   [bin list 1024 i32][wave counts 16 i32][per wave: 72 i32 pair prefix (reused as the item prefix of the fused
+  //   [bin list 2048 u16][wave counts 16 i32][per wave: 72 i32 pair prefix (reused as the item prefix of the fused
   //   tail)][per wave: 64 u32 pair decode info][per wave: 64 i32 list lengths][per wave: 64 u64 hide keys]
   //   [staged bbox 2x64 float4][staged records 2x320 float4][keys]
-  int32_t* s_bin = reinterpret_cast<int32_t*>(smem);
-  int32_t* s_wcnt = s_bin + kBinCap;
+  uint16_t* s_bin = reinterpret_cast<uint16_t*>(smem);
+  int32_t* s_wcnt = reinterpret_cast<int32_t*>(s_bin + kBinCap);
   int32_t* s_fpre_all = s_wcnt + 16;
   uint32_t* s_finfo_all = reinterpret_cast<uint32_t*>(s_fpre_all + 4 * kPreStride);
   int32_t* s_cnt_all = reinterpret_cast<int32_t*>(s_finfo_all + 4 * 64);
@@ -175,10 +183,11 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(s_rec + 2 * kSub * 5);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bins_per_img = P.nbx * P.nby;
-  const int n = blockIdx.x / bins_per_img;
-  const int b = blockIdx.x - n * bins_per_img;
-  const int by = b / P.nbx, bx = b - by * P.nbx;
+  // workgroup order: bins from the image centre outwards (rows, then columns), image index fastest -- the bins that
+  // hold the object, the long-running ones, start first and the empty border bins fill the gaps at the end
+  const int n = blockIdx.x % P.N;
+  const int b = blockIdx.x / P.N;
+  const int by = centre_out(b / P.nbx, P.nby), bx = centre_out(b % P.nbx, P.nbx);
   const int H = P.H, W = P.W, K = P.K;
 
   // bin extents in pixel-centre NDC (columns x0..x1, rows y0..y1, clamped to the image)
@@ -240,26 +249,33 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 
   const int64_t f0 = P.first[n];
   const int nf = (int)P.nfaces[n];
+  unsigned long long* wt = P.tim ? P.tim + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+  if (MODE == 2 && wt && lane == 0) { wt[0] = wall_clock64(); wt[1] = clock64(); }
+  unsigned long long t_scan = 0;
 
   for (int rbase = 0; rbase < nf; rbase += kBinCap) {
-    // ---- coarse: wave w scans faces [rbase + 256 w, +256) of this round (independent bbox loads per lane).  The
-    //      survivors are packed into one bin list, nearer half first (by nearest-corner depth against the midpoint of
-    //      the bin's depth range), ascending face index inside each half: the fused blend can then skip most of the
-    //      far side of a closed mesh (z_hide below).  Order never changes results -- selection is by (depth, face).
-    const int wbase = rbase + wave * 256;
-    float4 bbv[4];
-    float zv[4];
+    // ---- coarse: the round's faces (up to 2048) are split evenly over the waves, wave w scans a contiguous range
+    //      (independent bbox loads per lane).  The survivors are packed into one bin list, nearer half first (by
+    //      nearest-corner depth against the midpoint of the bin's depth range), ascending face index inside each
+    //      half: the fused blend can then skip most of the far side of a closed mesh (z_hide below).  Order never
+    //      changes results -- selection is by (depth, face).
+    const int fbase = (int32_t)f0 + rbase;  // packed index of the round's first face: face = fbase + s_bin[i]
+    const int per = ((min(nf - rbase, kBinCap) + 255) >> 8) << 6;  // faces per wave (multiple of 64)
+    const int wbase = rbase + wave * per;
+    float4 bbv[kScanQ];
+    float zv[kScanQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kScanQ; ++q) {
       const int f = wbase + q * 64 + lane;
-      bbv[q] = (f < nf) ? P.bbox[f0 + f] : make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
-      zv[q] = (MODE == 2 && f < nf) ? P.fz[f0 + f] : 0.0f;
+      const bool in = (q * 64 < per) && (f < nf);
+      bbv[q] = in ? P.bbox[f0 + f] : make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
+      zv[q] = (MODE == 2 && in) ? P.fz[f0 + f] : 0.0f;
     }
-    unsigned long long pm[4];
+    unsigned long long pm[kScanQ];
     int wc = 0;
     float zlo = __builtin_inff(), zhi = -__builtin_inff();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kScanQ; ++q) {
       const bool pass = bbox_overlap(bbv[q], bxc_lo, bxc_hi, byc_lo, byc_hi);
       pm[q] = __ballot(pass);
       wc += __popcll(pm[q]);
@@ -288,10 +304,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       }
       zmid = 0.5f * (a + b2);
     }
-    unsigned long long nm[4];  // passing faces of the near half
+    unsigned long long nm[kScanQ];  // passing faces of the near half
     int wn = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kScanQ; ++q) {
       nm[q] = (MODE == 2) ? __ballot(((pm[q] >> lane) & 1ull) && zv[q] <= zmid) : pm[q];
       wn += __popcll(nm[q]);
     }
@@ -310,9 +326,9 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       int pos_near = pre_near, pos_far = near_n + (pre_all - pre_near);
       const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < kScanQ; ++q) {
         const unsigned long long fm = pm[q] & ~nm[q];
-        const int fid = (int32_t)(f0 + wbase + q * 64 + lane);
+        const uint16_t fid = (uint16_t)(wave * per + q * 64 + lane);
         if ((nm[q] >> lane) & 1ull) s_bin[pos_near + __popcll(nm[q] & lt)] = fid;
         else if ((fm >> lane) & 1ull) s_bin[pos_far + __popcll(fm & lt)] = fid;
         pos_near += __popcll(nm[q]);
@@ -320,6 +336,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       }
     }
     __syncthreads();
+    if (MODE == 2 && P.tim) { t_scan = wall_clock64(); if (rbase == 0 && lane == 0) wt[15] = t_scan; }
     if (list_n == 0) continue;
 
     // ---- fine: 64 bin faces at a time; their bboxes / records are staged in LDS by the whole workgroup (next step's
@@ -328,9 +345,9 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     float4 r_bb = make_float4(0, 0, 0, 0), r_r0 = r_bb, r_r1 = r_bb;
     auto stage_load = [&](int c) {
       const int cntc = min(kSub, list_n - c * kSub);
-      if (tid < cntc) r_bb = P.bbox[s_bin[c * kSub + tid]];
-      if (tid < cntc * 5) r_r0 = P.rec[5 * (size_t)s_bin[c * kSub + tid / 5] + tid % 5];
-      if (tid + 256 < cntc * 5) r_r1 = P.rec[5 * (size_t)s_bin[c * kSub + (tid + 256) / 5] + (tid + 256) % 5];
+      if (tid < cntc) r_bb = P.bbox[fbase + s_bin[c * kSub + tid]];
+      if (tid < cntc * 5) r_r0 = P.rec[5 * (size_t)(fbase + s_bin[c * kSub + tid / 5]) + tid % 5];
+      if (tid + 256 < cntc * 5) r_r1 = P.rec[5 * (size_t)(fbase + s_bin[c * kSub + (tid + 256) / 5]) + (tid + 256) % 5];
     };
     auto stage_write = [&](int c) {
       const int cntc = min(kSub, list_n - c * kSub);
@@ -345,7 +362,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     __syncthreads();
     // one face of the staged chunk against this lane's own pixel (lane = pixel); list state in registers
     auto lockstep_face = [&](int c, int src, const float4* bbs, const float4* rcs) {
-      const int ufid = s_bin[c * kSub + src];  // wave-uniform
+      const int ufid = fbase + s_bin[c * kSub + src];  // wave-uniform
       const float4 ubb = bbs[src];
       const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
                                   rcs[src * 5 + 4]);
@@ -399,7 +416,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           const unsigned long long m = __ballot(pass);
           if (pass) {
             const int pos = tl_count + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < P.tl_cap) P.tl_lists[tile_id * P.tl_cap + pos] = s_bin[c * kSub + lane];
+            if (pos < P.tl_cap) P.tl_lists[tile_id * P.tl_cap + pos] = fbase + s_bin[c * kSub + lane];
           }
           tl_count += __popcll(m);
         } else if (MODE == 0) {
@@ -520,7 +537,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                   if (hit) {
                     const bool hides = hides_rest(ev.sd, P.sigma, P.mode);
                     const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
-                                                   ((unsigned)s_bin[c * kSub + src] << 1) | (hides ? 1u : 0u);
+                                                   ((unsigned)(fbase + s_bin[c * kSub + src]) << 1) | (hides ? 1u : 0u);
                     if (hides && key < hk) { atomicMin(&s_hide[pl], key); hk = key; improved = true; }
                     if (key <= hk) {
                       const int slot = atomicAdd(&s_cnt[pl], 1);
@@ -551,6 +568,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   if (!tile_live) return;
 
   if (MODE == 2) {
+    if (wt && lane == 0) { wt[2] = wall_clock64(); }
     // ---- fused shading.  (a) per pixel: drop the hits behind the nearest one that hides the rest, sort what is left
     //      front to back (in place; that hit, if any, comes last);  (b) the (pixel, layer) items of the whole tile
     //      are dealt out evenly over the 64 lanes -- any lane can evaluate any item -- so every lane stays busy
@@ -574,6 +592,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       if (hide_key != ~0ull) n_rel = j;
     }
     if (!pix_live) n_rel = 0;
+    { const int mc = wt ? wave_max(cnt) : 0; if (wt && lane == 0) { wt[3] = wall_clock64(); wt[7] = (unsigned long long)mc; } }
     constexpr int kDeep = 8;
     {
       // short lists: per-lane selection sort
@@ -615,6 +634,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         }
       }
     }
+    if (wt && lane == 0) wt[4] = wall_clock64();
     const int m = n_rel;  // layers of this pixel that matter, front to back in slots [0, m)
     int incl = m;
 #pragma unroll
@@ -626,7 +646,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     const int total = __builtin_amdgcn_readlane(incl, 63);
     int* s_pre = s_fpre_all + wave * kPreStride;
     s_pre[lane] = pre;
-    int32_t* lay = P.layers + tile_id * (int64_t)K * 6 * 64 + lane;  // [K][6 words][64 lanes]
+    int32_t* lay_tile = P.layers + tile_id * (int64_t)K * 6 * 64;  // [K][6 words][64 lanes]
+    int32_t* lay = lay_tile + lane;
     float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
     for (int base = 0; base < total; base += 64) {
       const int item = base + lane;
@@ -642,15 +663,23 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         const int fid = key_face(key);
         const float qx = pix_to_ndc(W - 1 - (tx0 + (l & 7)), W, H), qy = pix_to_ndc(H - 1 - (ty0 + (l >> 3)), H, W);
         const Face fc = load_face(P.rec, fid);
+        const float* fu = face_uv_row(P, n, fid);
+        const float fu0 = fu[0], fu1 = fu[1], fu2 = fu[2], fu3 = fu[3], fu4 = fu[4], fu5 = fu[5];
         Eval ev;
         eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
         va = layer_alpha(ev.sd, true, P.sigma, P.mode);
-        const float* fu = face_uv_row(P, n, fid);
-        const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
-        const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
+        const float u = (ev.c0 * fu0 + ev.c1 * fu2) + ev.c2 * fu4;
+        const float v = (ev.c0 * fu1 + ev.c1 * fu3) + ev.c2 * fu5;
         const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
         sample_rgb(map, bl, P.Ht, P.Wt, vr, vg, vb);
         if (P.use_amb) { vr *= P.amb[0]; vg *= P.amb[1]; vb *= P.amb[2]; }
+        // the layer record for the backward, written by whoever computed it (plane 1 is unused)
+        int32_t* le = lay_tile + (int64_t)k * 6 * 64 + l;
+        le[0] = fid;
+        le[128] = __float_as_int(va);
+        le[192] = __float_as_int(vr);
+        le[256] = __float_as_int(vg);
+        le[320] = __float_as_int(vb);
       }
       // owners composite their items of this batch, in depth order
       const int s0 = max(pre, base), e0 = min(pre + m, base + 64);
@@ -660,14 +689,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         const float a = __shfl(va, src, 64), cr = __shfl(vr, src, 64), cg = __shfl(vg, src, 64),
                     cb = __shfl(vb, src, 64);
         if (s0 + t < e0) {
-          const int kk = s0 + t - pre;
-          int32_t* le = lay + (int64_t)kk * 6 * 64;
-          le[0] = key_face(keys.get(kk));
-          le[64] = __float_as_int(occ);
-          le[128] = __float_as_int(a);
-          le[192] = __float_as_int(cr);
-          le[256] = __float_as_int(cg);
-          le[320] = __float_as_int(cb);
           r += occ * a * cr; g += occ * a * cg; b += occ * a * cb;
           occ = occ * (1.0f - a);
         }
@@ -682,6 +703,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       img[2 * hw] = b + occ * 1.0f * P.bg[2];
       img[3 * hw] = 1.0f - occ;
     }
+    if (wt && lane == 0) { wt[5] = wall_clock64(); wt[6] = (unsigned long long)total; wt[14] = clock64(); }
     return;
   }
 
@@ -729,7 +751,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   }
 }
 
-constexpr size_t kRasterFixedLds = (size_t)kBinCap * 4 + 64 + 4 * kPreStride * 4 + 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 8 +
+constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4 + 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 8 +
                                    2 * kSub * 16 + 2 * kSub * 5 * 16;
 
 // K-list slots per lane kept in LDS: all K when they fit two workgroups per CU, else what fits (the rest spills)
@@ -743,7 +765,9 @@ size_t raster_spill_bytes(int N, int H, int W, int K) {
   return over <= 0 ? 0 : (size_t)N * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)over * 64 * 8;
 }
 
+unsigned long long* g_dev_tim = nullptr;
 template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
+  P.tim = g_dev_tim;
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
   P.cap = (MODE == 1) ? 1 : raster_cap(P.K);
@@ -951,10 +975,11 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = P.H, W = P.W, K = P.K;
   const int TW = (W + 7) / 8;
-  const int bins_per_img = P.nbx * P.nby;
-  const int n = blockIdx.x / bins_per_img;
-  const int b = blockIdx.x - n * bins_per_img;
-  const int by = b / P.nbx, bx = b - by * P.nbx;
+  // workgroup order: bins from the image centre outwards (rows, then columns), image index fastest -- the bins that
+  // hold the object, the long-running ones, start first and the empty border bins fill the gaps at the end
+  const int n = blockIdx.x % P.N;
+  const int b = blockIdx.x / P.N;
+  const int by = centre_out(b / P.nbx, P.nby), bx = centre_out(b % P.nbx, P.nbx);
   const int tx0 = bx * 16 + (wave & 1) * 8, ty0 = by * 16 + (wave >> 1) * 8;
   const bool tile_live = (tx0 < W) && (ty0 < H);
   const int x = tx0 + (lane & 7), y = ty0 + (lane >> 3);
@@ -989,20 +1014,30 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       const float* gi = P.gimage + (int64_t)n * 4 * hw + (int64_t)y * W + x;
       g0 = gi[0]; g1 = gi[hw]; g2 = gi[2 * hw]; g3 = gi[3 * hw];
     }
-    // ---- (a) per pixel, back to front, from what the forward saved: dL/dalpha_k and the colour weight occ_k a_k
+    // ---- (a) per pixel, from the (alpha, colour) the forward saved per layer: first front to back, the
+    //      transmittance in front of every layer (the forward's own multiplication sequence, so the same bits), then
+    //      back to front, dL/dalpha_k and the colour weight occ_k a_k
     {
+      float occ = 1.0f;
+      for (int k = 0; k < maxm; ++k) {
+        if (k >= m) continue;
+        const float a = __int_as_float(lay[(int64_t)k * 6 * 64 + 128]);
+        float* sc = scr_tile + (int64_t)k * 2 * 64 + lane;
+        sc[0] = occ;
+        sc[64] = occ * a;
+        occ = occ * (1.0f - a);
+      }
       float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
       float trans = 1.0f;
       for (int k = maxm - 1; k >= 0; --k) {
         if (k >= m) continue;
         const int32_t* le = lay + (int64_t)k * 6 * 64;
-        const float occ = __int_as_float(le[64]), a = __int_as_float(le[128]);
+        const float a = __int_as_float(le[128]);
         const float cr = __int_as_float(le[192]), cgc = __int_as_float(le[256]), cb = __int_as_float(le[320]);
-        const float cg = g0 * cr + g1 * cgc + g2 * cb;
-        const float ga = occ * (cg - behind) + g3 * occ * trans;
         float* sc = scr_tile + (int64_t)k * 2 * 64 + lane;
-        sc[0] = ga;
-        sc[64] = occ * a;
+        const float occ = sc[0];
+        const float cg = g0 * cr + g1 * cgc + g2 * cb;
+        sc[0] = occ * (cg - behind) + g3 * occ * trans;
         behind = a * cg + (1.0f - a) * behind;
         trans = trans * (1.0f - a);
       }
@@ -1472,6 +1507,7 @@ int fill_shade_params(ShadeParams& P, const int32_t* p2f, const float* bary, con
 extern "C" {
 
 const char* ur_last_error(void) { return g_err; }
+void ur_dev_set_timing(void* p) { g_dev_tim = (unsigned long long*)p; }
 int ur_abi_version(void) { return 1; }
 
 size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
