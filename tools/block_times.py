@@ -36,19 +36,12 @@ print("waves", t.shape[0], "with tail", int(live.sum()), "kernel span us", float
 show("start", w[:, 0] - t0)
 show("scan round 0", w[:, 15] - w[:, 0])
 show("fine", w[:, 2] - w[:, 15])
-show("tail: compaction", w[:, 3] - w[:, 2])
-show("tail: sort", w[:, 4] - w[:, 3])
-show("tail: items", w[:, 5] - w[:, 4])
+show("tail (all)", w[:, 5] - w[:, 2])
 show("whole wave", w[:, 5] - w[:, 0])
-items = w[:, 6]; mc = w[:, 7]
-nb = torch.ceil(items / 64)
-print("item batches: total", float(nb.sum()), "us per batch (items phase sum / batches)", float(us(w[:, 5] - w[:, 4]).sum() / nb.sum()))
-print("maxcnt before tail compaction: p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(mc.quantile(q).tolist()))
-for lo, hi in ((0, 9), (9, 20), (20, 51)):
-    sel = (mc > lo) & (mc <= hi)
-    if sel.any():
-        print("  waves with maxcnt in (%d,%d]: %d ; compaction us mean %.1f ; sort mean %.1f ; items mean %.1f" % (lo, hi, int(sel.sum()), float(us(w[sel, 3] - w[sel, 2]).mean()), float(us(w[sel, 4] - w[sel, 3]).mean()), float(us(w[sel, 5] - w[sel, 4]).mean())))
-
-long = (w[:, 5] - w[:, 0]) > 2000
-mhz = (w[long, 14] - w[long, 1]) / (w[long, 5] - w[long, 0]) * 100.0
-print("shader clock seen by waves longer than 20 us: MHz p10 %.0f p50 %.0f p90 %.0f" % tuple(mhz.quantile(torch.tensor([.1, .5, .9], dtype=torch.double)).tolist()))
+fine = us(w[:, 2] - w[:, 15])
+print("fine phase: batches total %.0f pairs total %.0f (fill %.2f) faces(rects) total %.0f chunks total %.0f" % (float(w[:, 8].sum()), float(w[:, 9].sum()), float(w[:, 9].sum() / (64 * w[:, 8].sum())), float(w[:, 7].sum()), float(w[:, 12].sum())))
+print("fine wave-us: total %.0f ; barrier wait+stage write %.0f ; chunk setup (incl. stage load issue) %.0f ; rest (batches) %.0f -> us per batch %.2f" % (float(fine.sum()), float(us(w[:, 10]).sum()), float(us(w[:, 11]).sum()), float((fine - us(w[:, 10]) - us(w[:, 11])).sum()), float((fine - us(w[:, 10]) - us(w[:, 11])).sum() / w[:, 8].sum())))
+hv = torch.argsort(fine, descending=True)[:6]
+for i in hv.tolist():
+    print("  heavy wave: fine %.1f us, batches %d, pairs %d, rects %d, chunks %d, list_n %d, barrier %.1f, setup %.1f, compactions %d taking %.1f us" % (float(fine[i]), int(w[i, 8]), int(w[i, 9]), int(w[i, 7]), int(w[i, 12]), int(w[i, 13]), float(us(w[i, 10])), float(us(w[i, 11])), int(w[i, 4]), float(us(w[i, 3]))))
+print("in-loop compactions: %d taking %.0f wave-us" % (int(w[:, 4].sum()), float(us(w[:, 3]).sum())))

@@ -1,0 +1,42 @@
+"""dev helper: host-side enqueue time per step vs GPU time per step for the bench workload."""
+import os, sys, time, math
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unicorn_amd import native, synth
+from unicorn_amd.renderer import Renderer
+from unicorn_amd.structures import Meshes, TexturesUV
+dev = torch.device("cuda", 0)
+B, H, K = 32, 128, 50
+sc = synth.make_scene(B, level=3, tex_size=64, seed=0, device=dev)
+rend = Renderer(H, cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=1e-4).to(dev)
+verts = sc["verts"].requires_grad_(True); maps = sc["maps"].requires_grad_(True)
+R = sc["R"].requires_grad_(True); T = sc["T"].requires_grad_(True)
+fb, ub = sc["faces"][None].expand(B, -1, -1), sc["verts_uvs"][None].expand(B, -1, -1)
+cot = torch.randn(B, 4, H, H, device=dev)
+def step():
+    for t in (verts, maps, R, T): t.grad = None
+    meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
+    img = rend(meshes, R, T)
+    img.backward(cot)
+for _ in range(20): step()
+torch.cuda.synchronize()
+n = 200
+t0 = time.perf_counter()
+for _ in range(n): step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host enqueue per step: %.1f us ; wall per step incl. drain: %.1f us" % ((t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
+# forward only / pieces
+def fwd_only():
+    meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
+    return rend(meshes, R, T)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n): img = fwd_only()
+t1 = time.perf_counter(); torch.cuda.synchronize()
+print("forward host enqueue per step: %.1f us" % ((t1 - t0) / n * 1e6))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(100): step()
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(25)

@@ -127,7 +127,7 @@ constexpr int kScanQ = 8;         // faces per lane per scan round
 constexpr int kBinCap = 256 * kScanQ;  // faces per scan round = bin-list entries (u16 offsets into the round)
 constexpr int kSub = 64;         // faces staged in LDS per fine step
 constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU
-constexpr int kPreStride = 72;   // ints per wave in the pair-prefix array (65 used)
+constexpr int kPreStride = 96;   // ints per wave in the pair-prefix array: 65 prefix entries, then 64 byte marks
 
 // r-th index of 0..n-1 counted from the centre outwards: c, c-1, c+1, c-2, ...
 __device__ __forceinline__ int centre_out(int r, int n) {
@@ -135,10 +135,37 @@ __device__ __forceinline__ int centre_out(int r, int n) {
   return (r & 1) ? c - d : c + d;
 }
 
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+// Wave-wide inclusive scans on the VALU's data-parallel-primitive lanes (row shifts inside a 16-lane row, then the
+// two row broadcasts): six VALU operations, where a __shfl_up ladder is six dependent trips through the LDS crossbar.
+// `ident` is the operation's neutral element (what a lane combines with when it has no source lane).
+#define UR_SCAN_STEP(CTRL, ROWMASK) v = op(v, __builtin_amdgcn_update_dpp(ident, v, CTRL, ROWMASK, 0xf, false))
+template <class Op> __device__ __forceinline__ int wave_scan(int v, int ident, Op op) {
+  UR_SCAN_STEP(0x111, 0xf);  // row_shr:1
+  UR_SCAN_STEP(0x112, 0xf);  // row_shr:2
+  UR_SCAN_STEP(0x114, 0xf);  // row_shr:4
+  UR_SCAN_STEP(0x118, 0xf);  // row_shr:8
+  UR_SCAN_STEP(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+  UR_SCAN_STEP(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
   return v;
+}
+#undef UR_SCAN_STEP
+__device__ __forceinline__ int wave_scan_add(int v) {
+  return wave_scan(v, 0, [](int a, int b) { return a + b; });
+}
+__device__ __forceinline__ int wave_scan_max(int v) {  // v >= 0
+  return wave_scan(v, 0, [](int a, int b) { return max(a, b); });
+}
+// maximum over the wave of non-negative ints, in every lane
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_scan_max(v), 63); }
+__device__ __forceinline__ float wave_fmin(float v) {
+  const int r = wave_scan(__float_as_int(v), __float_as_int(__builtin_inff()),
+                          [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); });
+  return __int_as_float(__builtin_amdgcn_readlane(r, 63));
+}
+__device__ __forceinline__ float wave_fmax(float v) {
+  const int r = wave_scan(__float_as_int(v), __float_as_int(-__builtin_inff()),
+                          [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); });
+  return __int_as_float(__builtin_amdgcn_readlane(r, 63));
 }
 
 __device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float xc_hi, float yc_lo, float yc_hi) {
@@ -196,19 +223,24 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   const float bxc_hi = pix_to_ndc(W - 1 - bx0, W, H), bxc_lo = pix_to_ndc(W - 1 - bx1, W, H);
   const float byc_hi = pix_to_ndc(H - 1 - by0, H, W), byc_lo = pix_to_ndc(H - 1 - by1, H, W);
 
-  // this wave's tile
-  const int tx0 = bx0 + (wave & 1) * kTile, ty0 = by0 + (wave >> 1) * kTile;
+  // this wave's 64 pixels.  MODE 1 (tile lists): the 8x8 tile (wave & 1, wave >> 1) of the bin.  Otherwise every
+  // second column / row of the bin starting at (wave & 1, wave >> 1): the four waves of a workgroup then see almost
+  // the same load whatever the bin holds (a silhouette through one corner would otherwise leave three waves idle).
+  const int xs = (MODE == 1) ? 1 : 2;                 // pixel stride inside the wave
+  const int tx0 = bx0 + (wave & 1) * (MODE == 1 ? kTile : 1), ty0 = by0 + (wave >> 1) * (MODE == 1 ? kTile : 1);
   const bool tile_live = (tx0 < W) && (ty0 < H);
-  const int tx1 = min(W, tx0 + kTile) - 1, ty1 = min(H, ty0 + kTile) - 1;
+  const int tx1 = min(W, tx0 + xs * (kTile - 1) + 1) - 1, ty1 = min(H, ty0 + xs * (kTile - 1) + 1) - 1;
   const float txc_hi = pix_to_ndc(W - 1 - tx0, W, H), txc_lo = pix_to_ndc(W - 1 - max(tx1, tx0), W, H);
   const float tyc_hi = pix_to_ndc(H - 1 - ty0, H, W), tyc_lo = pix_to_ndc(H - 1 - max(ty1, ty0), H, W);
 
   // this lane's pixel
-  const int x = tx0 + (lane & 7), y = ty0 + (lane >> 3);
+  const int x = tx0 + xs * (lane & 7), y = ty0 + xs * (lane >> 3);
   const bool pix_live = (x < W) && (y < H);
   const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
 
-  const int64_t tile_id = ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * ((W + 7) / 8) + (tx0 >> 3);
+  // index of this wave's pixel group in layers / spill / tile lists
+  const int64_t tile_id = (MODE == 1) ? ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * ((W + 7) / 8) + (tx0 >> 3)
+                                      : (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
   KeyList keys;
   keys.cap = P.cap;
   keys.lds = s_keys_all + (size_t)wave * P.cap * 64 + lane;
@@ -242,16 +274,16 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     for (int j = 0; j < 8; ++j) {
       pxc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), j));
       pyc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), j * 8));
-      livecols |= (tx0 + j < W) ? (1u << j) : 0u;
-      liverows |= (ty0 + j < H) ? (1u << j) : 0u;
+      livecols |= (tx0 + xs * j < W) ? (1u << j) : 0u;
+      liverows |= (ty0 + xs * j < H) ? (1u << j) : 0u;
     }
   }
 
   const int64_t f0 = P.first[n];
   const int nf = (int)P.nfaces[n];
   unsigned long long* wt = P.tim ? P.tim + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
-  if (MODE == 2 && wt && lane == 0) { wt[0] = wall_clock64(); wt[1] = clock64(); }
-  unsigned long long t_scan = 0;
+  if (MODE == 2 && wt && lane == 0) { wt[0] = wall_clock64(); }
+  unsigned long long t_scan = 0, d_bar = 0, d_setup = 0, n_batch = 0, n_pairs = 0, n_faces = 0, d_comp = 0, n_comp = 0;
 
   for (int rbase = 0; rbase < nf; rbase += kBinCap) {
     // ---- coarse: the round's faces (up to 2048) are split evenly over the waves, wave w scans a contiguous range
@@ -282,11 +314,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       if (MODE == 2 && pass) { zlo = min_s(zlo, zv[q]); zhi = max_s(zhi, zv[q]); }
     }
     if (MODE == 2) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        zlo = fminf(zlo, __shfl_xor(zlo, off, 64));
-        zhi = fmaxf(zhi, __shfl_xor(zhi, off, 64));
-      }
+      zlo = wave_fmin(zlo);
+      zhi = wave_fmax(zhi);
     }
     if (lane == 0) {
       s_wcnt[wave] = wc;
@@ -405,6 +434,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 
     for (int c = 0; c < nsub; ++c) {
       if (c + 1 < nsub) stage_load(c + 1);
+      const unsigned long long t_c0 = P.tim ? wall_clock64() : 0;
       if (tile_live) {
         const int cntc = min(kSub, list_n - c * kSub);
         const float4* bbs = s_bb + (c & 1) * kSub;
@@ -446,12 +476,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           const unsigned long long m = __ballot(area > 0);
           const int nfp = __popcll(m);
           if (nfp > 0) {
-            int incl = area;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-              const int t = __shfl_up(incl, off, 64);
-              if (lane >= off) incl += t;
-            }
+            const int incl = wave_scan_add(area);
             const int total_pairs = __builtin_amdgcn_readlane(incl, 63);
             if (area > 0) {
               const int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -466,11 +491,14 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
             const unsigned cinfo = s_finfo[lane];
             const int lim = min(P.cap, K);
             int r0 = 0;
+            if (P.tim) { d_setup += wall_clock64() - t_c0; n_pairs += total_pairs; n_faces += nfp; }
             while (r0 < nfp) {
               // how many faces can go the pair way: each adds at most one entry to any pixel's list, and no list
               // may pass K (there the exact keep-the-K-smallest rule takes over, lane = pixel)
               int c2 = s_cnt[lane];
               int cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
+              const unsigned long long t_k0 = P.tim ? wall_clock64() : 0;
+              const bool do_comp = any_stale && cmax + (nfp - r0) > lim;
               if (any_stale && cmax + (nfp - r0) > lim) {
                 // compact the lists whose hide key moved: drop what the nearest hiding hit made irrelevant
                 const unsigned long long hk = s_hide[lane];
@@ -487,6 +515,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 any_stale = false;
                 cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
               }
+              if (P.tim && do_comp) { d_comp += wall_clock64() - t_k0; ++n_comp; }
               const int room = K - cmax;
               if (room < min(nfp - r0, 4)) {
                 const int r1 = min(nfp, r0 + 8);
@@ -507,33 +536,40 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
               const int pbeg = __builtin_amdgcn_readlane(cpre, r0), pend = __builtin_amdgcn_readlane(cend, r1 - 1);
               bool improved = false;
               for (int pb = pbeg; pb < pend; pb += 64) {
+                ++n_batch;
+                const bool stamp = P.tim && n_batch == 3;
+                unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+                if (stamp) ts0 = wall_clock64();
                 const int pidx = pb + lane;
                 const bool act = pidx < pend;
-                // the faces this batch touches (a few): pick mine by comparing against their first pair
-                unsigned long long fm = __ballot(lane >= r0 && lane < r1 && cend > pb && cpre < pb + 64);
-                int mypre = 0;
-                unsigned info = 0;
-                while (fm) {
-                  const int i = __builtin_ctzll(fm);
-                  fm &= fm - 1;
-                  const int pi = __builtin_amdgcn_readlane(cpre, i);
-                  const unsigned ii = (unsigned)__builtin_amdgcn_readlane((int)cinfo, i);
-                  if (pidx >= pi) { mypre = pi; info = ii; }
-                }
+                // which face does pair pidx belong to?  The faces that start inside the batch mark their first
+                // pair's slot with their rank + 1, slot 0 takes the face that holds pair pb, and a running maximum
+                // spreads the marks to the right.
+                unsigned char* marks = reinterpret_cast<unsigned char*>(s_fpre + 68);
+                marks[lane] = 0;
+                const bool mine = lane >= r0 && lane < r1 && cend > pb && cpre < pb + 64;
+                const int rfirst = __builtin_ctzll(__ballot(mine));
+                if (mine && cpre > pb) marks[cpre - pb] = (unsigned char)(lane + 1);
+                const int rr = wave_scan_max(lane == 0 ? rfirst + 1 : (int)marks[lane]) - 1;
+                const int mypre = s_fpre[rr];
+                const unsigned info = s_finfo[rr];
                 const int q = pidx - mypre;
                 const int w = (int)((info >> 12) & 15u);
                 const int dy = (q * (int)(info >> 16)) >> 15, dx = q - dy * w;
                 const int src = (int)(info & 63u);
                 const int pl = act ? ((((int)((info >> 9) & 7u) + dy) << 3) | ((int)((info >> 6) & 7u) + dx)) : lane;
                 const float qx = __shfl(px, pl, 64), qy = __shfl(py, pl, 64);
+                if (stamp) { asm volatile("" :: "v"(qx), "v"(qy)); ts2 = wall_clock64(); }
                 if (act) {
                   const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
                                               rcs[src * 5 + 4]);
                   unsigned long long hk = s_hide[pl];
+                  if (stamp) { asm volatile("" :: "v"(fc.v0x), "v"(fc.zmin), "v"(hk)); ts3 = wall_clock64(); }
                   bool hit = true;
                   if (can_cull && hk != ~0ull) hit = !(fc.zmin * 0.9999f > __uint_as_float((unsigned)(hk >> 32)));
                   Eval ev;
                   if (hit) hit = eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
+                  if (stamp) { asm volatile("" :: "v"(ev.sd), "v"(ev.pz)); ts4 = wall_clock64(); }
                   if (hit) {
                     const bool hides = hides_rest(ev.sd, P.sigma, P.mode);
                     const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
@@ -553,9 +589,12 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           }
         }
       }
+      const unsigned long long t_c1 = P.tim ? wall_clock64() : 0;
       if (c + 1 < nsub) stage_write(c + 1);
       __syncthreads();
+      if (P.tim) d_bar += wall_clock64() - t_c1;
     }
+    if (MODE == 2 && wt && lane == 0) { wt[12] = nsub; wt[13] = list_n; }
   }
 
   if (MODE == 1) {
@@ -568,7 +607,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   if (!tile_live) return;
 
   if (MODE == 2) {
-    if (wt && lane == 0) { wt[2] = wall_clock64(); }
+    if (wt && lane == 0) { wt[2] = wall_clock64(); wt[8] = n_batch; wt[9] = n_pairs; wt[10] = d_bar; wt[11] = d_setup; wt[7] = n_faces; wt[3] = d_comp; wt[4] = n_comp; }
     // ---- fused shading.  (a) per pixel: drop the hits behind the nearest one that hides the rest, sort what is left
     //      front to back (in place; that hit, if any, comes last);  (b) the (pixel, layer) items of the whole tile
     //      are dealt out evenly over the 64 lanes -- any lane can evaluate any item -- so every lane stays busy
@@ -592,7 +631,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       if (hide_key != ~0ull) n_rel = j;
     }
     if (!pix_live) n_rel = 0;
-    { const int mc = wt ? wave_max(cnt) : 0; if (wt && lane == 0) { wt[3] = wall_clock64(); wt[7] = (unsigned long long)mc; } }
     constexpr int kDeep = 8;
     {
       // short lists: per-lane selection sort
@@ -634,34 +672,35 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         }
       }
     }
-    if (wt && lane == 0) wt[4] = wall_clock64();
     const int m = n_rel;  // layers of this pixel that matter, front to back in slots [0, m)
-    int incl = m;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
+    const int incl = wave_scan_add(m);
     const int pre = incl - m;
     const int total = __builtin_amdgcn_readlane(incl, 63);
     int* s_pre = s_fpre_all + wave * kPreStride;
+    unsigned char* marks = reinterpret_cast<unsigned char*>(s_pre + 68);
     s_pre[lane] = pre;
+    // the staging buffers are dead once the fine step is over (every wave is past its last barrier): this wave's
+    // slice of them carries the batch's (alpha, r, g, b) from the lanes that computed them to the pixels' owners
+    float4* s_res = s_rec + wave * 64;
     int32_t* lay_tile = P.layers + tile_id * (int64_t)K * 6 * 64;  // [K][6 words][64 lanes]
     int32_t* lay = lay_tile + lane;
     float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
     for (int base = 0; base < total; base += 64) {
       const int item = base + lane;
+      // owner of item: the pixels whose first item falls inside the batch mark that slot with lane + 1, slot 0 takes
+      // the pixel that holds item `base`, and a running maximum spreads the marks to the right
+      marks[lane] = 0;
+      const int l0 = 63 - __builtin_clzll(__ballot(m > 0 && pre <= base));
+      if (m > 0 && pre > base && pre < base + 64) marks[pre - base] = (unsigned char)(lane + 1);
+      const int l = wave_scan_max(lane == 0 ? l0 + 1 : (int)marks[lane]) - 1;
       float va = 0.0f, vr = 0.0f, vg = 0.0f, vb = 0.0f;
       if (item < total) {
-        int l = 0;  // owner: the last lane whose first item is <= item
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-          if (s_pre[l + step] <= item) l += step;
         const int k = item - s_pre[l];
         const unsigned long long key = (k < P.cap) ? lds_base[(size_t)k * 64 + l]
                                                     : spill_base[(size_t)(k - P.cap) * 64 + l];
         const int fid = key_face(key);
-        const float qx = pix_to_ndc(W - 1 - (tx0 + (l & 7)), W, H), qy = pix_to_ndc(H - 1 - (ty0 + (l >> 3)), H, W);
+        const float qx = pix_to_ndc(W - 1 - (tx0 + xs * (l & 7)), W, H);
+        const float qy = pix_to_ndc(H - 1 - (ty0 + xs * (l >> 3)), H, W);
         const Face fc = load_face(P.rec, fid);
         const float* fu = face_uv_row(P, n, fid);
         const float fu0 = fu[0], fu1 = fu[1], fu2 = fu[2], fu3 = fu[3], fu4 = fu[4], fu5 = fu[5];
@@ -681,16 +720,15 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         le[256] = __float_as_int(vg);
         le[320] = __float_as_int(vb);
       }
+      s_res[lane] = make_float4(va, vr, vg, vb);
       // owners composite their items of this batch, in depth order
       const int s0 = max(pre, base), e0 = min(pre + m, base + 64);
-      const int nloop = __builtin_amdgcn_readfirstlane(wave_max(e0 - s0));
+      const int nloop = __builtin_amdgcn_readfirstlane(wave_max(max(e0 - s0, 0)));
       for (int t = 0; t < nloop; ++t) {
-        const int src = (s0 + t - base) & 63;
-        const float a = __shfl(va, src, 64), cr = __shfl(vr, src, 64), cg = __shfl(vg, src, 64),
-                    cb = __shfl(vb, src, 64);
         if (s0 + t < e0) {
-          r += occ * a * cr; g += occ * a * cg; b += occ * a * cb;
-          occ = occ * (1.0f - a);
+          const float4 c = s_res[s0 + t - base];
+          r += occ * c.x * c.y; g += occ * c.x * c.z; b += occ * c.x * c.w;
+          occ = occ * (1.0f - c.x);
         }
       }
     }
@@ -703,7 +741,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       img[2 * hw] = b + occ * 1.0f * P.bg[2];
       img[3 * hw] = 1.0f - occ;
     }
-    if (wt && lane == 0) { wt[5] = wall_clock64(); wt[6] = (unsigned long long)total; wt[14] = clock64(); }
+    if (wt && lane == 0) { wt[5] = wall_clock64(); }
     return;
   }
 
@@ -738,7 +776,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   // padding: for every pixel of the tile the slots [cnt, K) are written by lanes that sweep k (contiguous stores)
   for (int p = 0; p < 64; ++p) {
     const int pcnt = __builtin_amdgcn_readlane(cnt, p);
-    const int qx = tx0 + (p & 7), qy = ty0 + (p >> 3);
+    const int qx = tx0 + xs * (p & 7), qy = ty0 + xs * (p >> 3);
     if (qx >= W || qy >= H) continue;
     const int64_t qbase = (((int64_t)n * H + qy) * W + qx) * K;
     for (int k = pcnt + lane; k < K; k += 64) {
@@ -751,6 +789,9 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   }
 }
 
+// 64-pixel groups (one per wave) of an image: 4 per 16x16 bin
+size_t wave_groups(int H, int W) { return (size_t)((H + 15) / 16) * ((W + 15) / 16) * 4; }
+
 constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4 + 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 8 +
                                    2 * kSub * 16 + 2 * kSub * 5 * 16;
 
@@ -762,7 +803,7 @@ int raster_cap(int K) {
 
 size_t raster_spill_bytes(int N, int H, int W, int K) {
   const int over = K - raster_cap(K);
-  return over <= 0 ? 0 : (size_t)N * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)over * 64 * 8;
+  return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
 }
 
 unsigned long long* g_dev_tim = nullptr;
@@ -974,17 +1015,16 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   __shared__ int s_pre_all[4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = P.H, W = P.W, K = P.K;
-  const int TW = (W + 7) / 8;
-  // workgroup order: bins from the image centre outwards (rows, then columns), image index fastest -- the bins that
-  // hold the object, the long-running ones, start first and the empty border bins fill the gaps at the end
+  // same workgroup order and pixel ownership as the forward: bins centre-out with the image index fastest; wave w
+  // holds every second column / row of the bin from (w & 1, w >> 1)
   const int n = blockIdx.x % P.N;
   const int b = blockIdx.x / P.N;
   const int by = centre_out(b / P.nbx, P.nby), bx = centre_out(b % P.nbx, P.nbx);
-  const int tx0 = bx * 16 + (wave & 1) * 8, ty0 = by * 16 + (wave >> 1) * 8;
+  const int tx0 = bx * 16 + (wave & 1), ty0 = by * 16 + (wave >> 1);
   const bool tile_live = (tx0 < W) && (ty0 < H);
-  const int x = tx0 + (lane & 7), y = ty0 + (lane >> 3);
+  const int x = tx0 + 2 * (lane & 7), y = ty0 + 2 * (lane >> 3);
   const bool live = (x < W) && (y < H);
-  const int64_t tile_id = ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * TW + (tx0 >> 3);
+  const int64_t tile_id = (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
   const int32_t* lay_tile = P.layers + (tile_live ? tile_id : 0) * (int64_t)K * 6 * 64;  // [K][6][64]
   const int32_t* lay = lay_tile + lane;
   float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 2 * 64;         // [K][2][64]
@@ -1044,12 +1084,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     }
     // ---- (b) the tile's (pixel, layer) items dealt out evenly over the lanes: geometry is re-evaluated once per
     //      item, gradients go to the LDS tables
-    int incl = m;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
+    const int incl = wave_scan_add(m);
     const int pre = incl - m;
     const int total = __builtin_amdgcn_readlane(incl, 63);
     int* s_pre = s_pre_all + wave * 64;
@@ -1071,7 +1106,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       const int fid = le[0];
       const float a = __int_as_float(le[128]);
       const float ga = scr_tile[(int64_t)k * 2 * 64 + l], wgt = scr_tile[(int64_t)k * 2 * 64 + 64 + l];
-      const float px = pix_to_ndc(W - 1 - (tx0 + (l & 7)), W, H), py = pix_to_ndc(H - 1 - (ty0 + (l >> 3)), H, W);
+      const float px = pix_to_ndc(W - 1 - (tx0 + 2 * (l & 7)), W, H), py = pix_to_ndc(H - 1 - (ty0 + 2 * (l >> 3)), H, W);
       const Face fc = load_face(P.rec, fid);
       Eval ev;
       eval_face(fc, px, py, P.blur, clip, ev);
@@ -1657,11 +1692,11 @@ int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* 
 }
 
 size_t ur_backward_scratch_bytes(int N, int H, int W, int K) {
-  return (size_t)(N < 0 ? 0 : N) * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)K * 64 * 2 * 4;
+  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * (size_t)K * 64 * 2 * 4;
 }
 
 size_t ur_layers_elems(int N, int H, int W, int K) {
-  return (size_t)(N < 0 ? 0 : N) * ((H + 7) / 8) * ((W + 7) / 8) * (size_t)K * 64 * 6;
+  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * (size_t)K * 64 * 6;
 }
 
 static int fill_render_params(RasterParams& P, const int64_t* first, const int64_t* nfaces, int N, int H, int W,

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libunicorn_render.so")
+# UNICORN_RENDER_LIB: load another build of the same library (A/B timing of two builds on one box)
+LIB_PATH = os.environ.get("UNICORN_RENDER_LIB") or os.path.join(_HERE, "lib", "libunicorn_render.so")
 
 BLEND_HARD, BLEND_CLIP_INSIDE, BLEND_SIGMOID = 0, 1, 2
 
