@@ -129,6 +129,11 @@ constexpr int kSub = 64;         // faces staged in LDS per fine step
 constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU
 constexpr int kPreStride = 96;   // ints per wave in the pair-prefix array: 65 prefix entries, then 64 byte marks
 
+// where the per-pixel layer counts start inside `layers` (after the [group][K][6][64] records)
+__host__ __device__ inline int64_t layer_counts_offset(int N, int nbx, int nby, int K) {
+  return (int64_t)N * nbx * nby * 4 * K * 6 * 64;
+}
+
 // r-th index of 0..n-1 counted from the centre outwards: c, c-1, c+1, c-2, ...
 __device__ __forceinline__ int centre_out(int r, int n) {
   const int c = n >> 1, d = (r + 1) >> 1;
@@ -712,7 +717,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
         sample_rgb(map, bl, P.Ht, P.Wt, vr, vg, vb);
         if (P.use_amb) { vr *= P.amb[0]; vg *= P.amb[1]; vb *= P.amb[2]; }
-        // the layer record for the backward, written by whoever computed it (plane 1 is unused)
+        // the layer record for the backward, written by whoever computed it (plane 1, the transmittance in front of
+        // the layer, comes from the pixel's owner below)
         int32_t* le = lay_tile + (int64_t)k * 6 * 64 + l;
         le[0] = fid;
         le[128] = __float_as_int(va);
@@ -727,12 +733,13 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       for (int t = 0; t < nloop; ++t) {
         if (s0 + t < e0) {
           const float4 c = s_res[s0 + t - base];
+          lay[(int64_t)(s0 + t - pre) * 6 * 64 + 64] = __float_as_int(occ);
           r += occ * c.x * c.y; g += occ * c.x * c.z; b += occ * c.x * c.w;
           occ = occ * (1.0f - c.x);
         }
       }
     }
-    if (m < K) lay[(int64_t)m * 6 * 64] = -1;
+    P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] = m;  // per-pixel layer count
     if (pix_live) {
       const int64_t hw = (int64_t)H * W;
       float* img = P.image + (int64_t)n * 4 * hw + (int64_t)y * W + x;
@@ -1012,7 +1019,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   __shared__ double s_fval[kFaceSlots * 6];
   __shared__ int s_ttag[kTexSlots];
   __shared__ double s_tval[kTexSlots * 3];
-  __shared__ int s_pre_all[4 * 64];
+  __shared__ int s_pre_all[4 * 80];  // per wave: 64 item prefixes, then 64 byte marks
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = P.H, W = P.W, K = P.K;
   // same workgroup order and pixel ownership as the forward: bins centre-out with the image index fastest; wave w
@@ -1030,16 +1037,12 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 2 * 64;         // [K][2][64]
   float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
 
-  int m = 0;  // this pixel's layer count
-  if (tile_live) {
-    bool alive = live;
-    for (int k = 0; k < K; ++k) {
-      if (alive) alive = lay[(int64_t)k * 6 * 64] >= 0;
-      if (!__any(alive)) break;
-      m += alive ? 1 : 0;
-    }
-  }
+  unsigned long long* wt = P.tim ? P.tim + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+  if (wt && lane == 0) wt[0] = wall_clock64();
+  // this pixel's layer count (left by the forward)
+  const int m = (tile_live && live) ? P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] : 0;
   const int maxm = __builtin_amdgcn_readfirstlane(wave_max(m));
+  if (wt && lane == 0) wt[1] = wall_clock64();
   if (!__syncthreads_or(maxm > 0)) return;  // nothing rendered in this bin
   for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
   for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0;
@@ -1054,49 +1057,52 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       const float* gi = P.gimage + (int64_t)n * 4 * hw + (int64_t)y * W + x;
       g0 = gi[0]; g1 = gi[hw]; g2 = gi[2 * hw]; g3 = gi[3 * hw];
     }
-    // ---- (a) per pixel, from the (alpha, colour) the forward saved per layer: first front to back, the
-    //      transmittance in front of every layer (the forward's own multiplication sequence, so the same bits), then
-    //      back to front, dL/dalpha_k and the colour weight occ_k a_k
+    // ---- (a) per pixel, back to front, from what the forward saved per layer (transmittance in front, alpha,
+    //      colour): dL/dalpha_k and the colour weight occ_k a_k.  Two layers' loads are issued together.
     {
-      float occ = 1.0f;
-      for (int k = 0; k < maxm; ++k) {
-        if (k >= m) continue;
-        const float a = __int_as_float(lay[(int64_t)k * 6 * 64 + 128]);
-        float* sc = scr_tile + (int64_t)k * 2 * 64 + lane;
-        sc[0] = occ;
-        sc[64] = occ * a;
-        occ = occ * (1.0f - a);
-      }
       float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
       float trans = 1.0f;
-      for (int k = maxm - 1; k >= 0; --k) {
-        if (k >= m) continue;
-        const int32_t* le = lay + (int64_t)k * 6 * 64;
-        const float a = __int_as_float(le[128]);
-        const float cr = __int_as_float(le[192]), cgc = __int_as_float(le[256]), cb = __int_as_float(le[320]);
-        float* sc = scr_tile + (int64_t)k * 2 * 64 + lane;
-        const float occ = sc[0];
+      auto sweep = [&](int k, float occ, float a, float cr, float cgc, float cb) {
         const float cg = g0 * cr + g1 * cgc + g2 * cb;
+        float* sc = scr_tile + (int64_t)k * 2 * 64 + lane;
         sc[0] = occ * (cg - behind) + g3 * occ * trans;
+        sc[64] = occ * a;
         behind = a * cg + (1.0f - a) * behind;
         trans = trans * (1.0f - a);
+      };
+      for (int kb = maxm - 1; kb >= 0; kb -= 2) {
+        const int k1 = kb, k0 = kb - 1;
+        const bool h1 = k1 < m, h0 = k0 >= 0 && k0 < m;
+        const int32_t* l1 = lay + (int64_t)k1 * 6 * 64;
+        const int32_t* l0 = lay + (int64_t)(k0 < 0 ? 0 : k0) * 6 * 64;
+        float o1 = 0, a1 = 0, r1 = 0, gg1 = 0, b1 = 0, o0 = 0, a0 = 0, r0 = 0, gg0 = 0, b0 = 0;
+        if (h1) { o1 = __int_as_float(l1[64]); a1 = __int_as_float(l1[128]); r1 = __int_as_float(l1[192]);
+                  gg1 = __int_as_float(l1[256]); b1 = __int_as_float(l1[320]); }
+        if (h0) { o0 = __int_as_float(l0[64]); a0 = __int_as_float(l0[128]); r0 = __int_as_float(l0[192]);
+                  gg0 = __int_as_float(l0[256]); b0 = __int_as_float(l0[320]); }
+        if (h1) sweep(k1, o1, a1, r1, gg1, b1);
+        if (h0) sweep(k0, o0, a0, r0, gg0, b0);
       }
     }
+    if (wt && lane == 0) wt[2] = wall_clock64();
     // ---- (b) the tile's (pixel, layer) items dealt out evenly over the lanes: geometry is re-evaluated once per
     //      item, gradients go to the LDS tables
     const int incl = wave_scan_add(m);
     const int pre = incl - m;
     const int total = __builtin_amdgcn_readlane(incl, 63);
-    int* s_pre = s_pre_all + wave * 64;
+    int* s_pre = s_pre_all + wave * 80;
+    unsigned char* marks = reinterpret_cast<unsigned char*>(s_pre + 64);
     s_pre[lane] = pre;
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
     const bool clip = P.clip != 0;
     for (int base = 0; base < total; base += 64) {
       const int item = base + lane;
-      int l = 0;
-#pragma unroll
-      for (int step = 32; step > 0; step >>= 1)
-        if (s_pre[l + step] <= item) l += step;
+      // owner of item: pixels whose first item falls inside the batch mark that slot, slot 0 takes the pixel that
+      // holds item `base`, a running maximum spreads the marks to the right
+      marks[lane] = 0;
+      const int l0 = 63 - __builtin_clzll(__ballot(m > 0 && pre <= base));
+      if (m > 0 && pre > base && pre < base + 64) marks[pre - base] = (unsigned char)(lane + 1);
+      int l = wave_scan_max(lane == 0 ? l0 + 1 : (int)marks[lane]) - 1;
       if (item >= total) l = lane;
       // cotangent of the owner pixel (all lanes take part in the shuffles)
       const float q0 = __shfl(g0, l, 64), q1 = __shfl(g1, l, 64), q2 = __shfl(g2, l, 64);
@@ -1183,6 +1189,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     }
   }
 
+  if (wt && lane == 0) { wt[3] = wall_clock64(); wt[6] = (unsigned long long)maxm; }
   __syncthreads();
   if (P.gfv)
     for (int i = tid; i < kFaceSlots * 6; i += 256) {
@@ -1198,6 +1205,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       const float v = (float)s_tval[i];
       if (tag >= 0 && v != 0.0f) atomicAdd(gmap + (int64_t)tag * 3 + c, v);
     }
+  if (wt && lane == 0) wt[4] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1696,7 +1704,7 @@ size_t ur_backward_scratch_bytes(int N, int H, int W, int K) {
 }
 
 size_t ur_layers_elems(int N, int H, int W, int K) {
-  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * (size_t)K * 64 * 6;
+  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * ((size_t)K * 64 * 6 + 64);
 }
 
 static int fill_render_params(RasterParams& P, const int64_t* first, const int64_t* nfaces, int N, int H, int W,
@@ -1759,6 +1767,7 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   P.nby = (H + 15) / 16;
   const int64_t blocks = (int64_t)N * P.nbx * P.nby;
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
+  P.tim = g_dev_tim;
   hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
   return check_launch("k_render_bwd");
 }
