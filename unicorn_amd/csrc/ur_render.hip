@@ -985,19 +985,22 @@ constexpr int kTexSlots = 256;   // x 3 sums ; slot = 16x16 torus over (texel ro
 
 __device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, float px, float py, bool clip, float g0,
                                               float g1, float g2, float o[6]) {
+  // every quotient below is the correctly rounded one (div_by with RN reciprocals): same bits as plain divisions
   const float w0 = ev.w0, w1 = ev.w1, w2 = ev.w2;
   float gw0 = g0, gw1 = g1, gw2 = g2;
   if (clip) {
     const float c0 = max_s(w0, 0.0f), c1 = max_s(w1, 0.0f), c2 = max_s(w2, 0.0f);
     const float sraw = c0 + c1 + c2;
     const float s = max_s(sraw, 1e-5f);
+    const float is = 1.0f / s;
     const float gs = (sraw < 1e-5f) ? 0.0f : -(g0 * c0 + g1 * c1 + g2 * c2) / (s * s);
-    gw0 = (w0 > 0.0f) ? (g0 / s + gs) : 0.0f;
-    gw1 = (w1 > 0.0f) ? (g1 / s + gs) : 0.0f;
-    gw2 = (w2 > 0.0f) ? (g2 / s + gs) : 0.0f;
+    gw0 = (w0 > 0.0f) ? (div_by(g0, s, is) + gs) : 0.0f;
+    gw1 = (w1 > 0.0f) ? (div_by(g1, s, is) + gs) : 0.0f;
+    gw2 = (w2 > 0.0f) ? (div_by(g2, s, is) + gs) : 0.0f;
   }
-  const float ge0 = gw0 / f.denom, ge1 = gw1 / f.denom, ge2 = gw2 / f.denom;
-  const float gden = -(gw0 * w0 + gw1 * w1 + gw2 * w2) / f.denom;
+  const float ge0 = div_by(gw0, f.denom, f.idenom), ge1 = div_by(gw1, f.denom, f.idenom),
+              ge2 = div_by(gw2, f.denom, f.idenom);
+  const float gden = div_by(-(gw0 * w0 + gw1 * w1 + gw2 * w2), f.denom, f.idenom);
   float a0x = 0, a0y = 0, a1x = 0, a1y = 0, a2x = 0, a2y = 0;
   edge_bwd(px, py, f.v1x, f.v1y, f.v2x, f.v2y, ge0, a1x, a1y, a2x, a2y);
   edge_bwd(px, py, f.v2x, f.v2y, f.v0x, f.v0y, ge1, a2x, a2y, a0x, a0y);
@@ -1114,12 +1117,13 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       const float ga = scr_tile[(int64_t)k * 2 * 64 + l], wgt = scr_tile[(int64_t)k * 2 * 64 + 64 + l];
       const float px = pix_to_ndc(W - 1 - (tx0 + 2 * (l & 7)), W, H), py = pix_to_ndc(H - 1 - (ty0 + 2 * (l >> 3)), H, W);
       const Face fc = load_face(P.rec, fid);
+      const float* fup = face_uv_row(P, n, fid);
+      const float fu[6] = {fup[0], fup[1], fup[2], fup[3], fup[4], fup[5]};  // in flight with the record
       Eval ev;
       eval_face(fc, px, py, P.blur, clip, ev);
       const float gd = ga * layer_dalpha(ev.sd, a, true, P.sigma, P.mode);
       float o[6] = {0, 0, 0, 0, 0, 0};
       if (wgt != 0.0f) {
-        const float* fu = face_uv_row(P, n, fid);
         const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
         const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
         const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
@@ -1147,15 +1151,24 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
         if (gmap) {
           const int offs[4] = {onw, one, osw, ose};
           const float wts[4] = {bl.wnw, bl.wne, bl.wsw, bl.wse};
+          // texel (row, column) straight from the footprint: flipped rows Ht-1-y0 / Ht-2-y0, columns x0 / x0+1
+          const int r0 = P.Ht - 1 - bl.y0, c0 = bl.x0;
+          int hs[4], tx[4];
+          bool own[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int trow = r0 - (q >> 1), tcol = c0 + (q & 1);
+            tx[q] = trow * P.Wt + tcol;
+            hs[q] = ((trow & 15) << 4) | (tcol & 15);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) own[q] = (offs[q] >= 0) && lds_claim(s_ttag, hs[q], tx[q]);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             if (offs[q] < 0) continue;
-            const int texel = offs[q] / 3;
-            const int trow = texel / P.Wt, tcol = texel - trow * P.Wt;
-            const int h = ((trow & 15) << 4) | (tcol & 15);
-            if (lds_claim(s_ttag, h, texel)) {
+            if (own[q]) {
 #pragma unroll
-              for (int ch = 0; ch < 3; ++ch) atomicAdd(&s_tval[h * 3 + ch], (double)(gc[ch] * wts[q]));
+              for (int ch = 0; ch < 3; ++ch) atomicAdd(&s_tval[hs[q] * 3 + ch], (double)(gc[ch] * wts[q]));
             } else {
 #pragma unroll
               for (int ch = 0; ch < 3; ++ch) atomicAdd(gmap + offs[q] + ch, gc[ch] * wts[q]);

@@ -296,8 +296,12 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
     N, K = int(mesh_first_face.shape[0]), int(faces_per_pixel)
     Ht, Wt = maps.shape[1:3]
     dev = maps.device
-    gfv = torch.zeros(total_faces, 3, 3, dtype=torch.float32, device=dev) if need_face_verts else None
-    gmaps = torch.zeros_like(maps) if need_maps else None
+    # both accumulators come out of ONE zero-filled allocation (one fill launch instead of two)
+    n_fv = total_faces * 9 if need_face_verts else 0
+    n_fv_pad = (n_fv + 63) // 64 * 64
+    zeros = torch.zeros(n_fv_pad + (maps.numel() if need_maps else 0), dtype=torch.float32, device=dev)
+    gfv = zeros[:n_fv].view(total_faces, 3, 3) if need_face_verts else None
+    gmaps = zeros[n_fv_pad:].view(maps.shape) if need_maps else None
     scratch = torch.empty(int(lib().ur_backward_scratch_bytes(N, H, W, K)), dtype=torch.uint8, device=dev)
     with _on(maps), _timed("ur_render_layered_backward", maps):
         _check(lib().ur_render_layered_backward(

@@ -53,10 +53,25 @@ class TexturesUV:
         .expand): one (F,3,2) face-UV table then serves every mesh."""
         return self._faces_uvs.stride(0) == 0 and self._verts_uvs.stride(0) == 0
 
+    _uv_cache = {}  # (storage ptrs, versions, shapes) -> gathered face-UV table; see faces_verts_uvs
+
     def faces_verts_uvs(self):
-        """(face_uvs, shared): (F,3,2) with shared=True, else packed (N*F,3,2)."""
+        """(face_uvs, shared): (F,3,2) with shared=True, else packed (N*F,3,2).  The reference rebuilds the textures
+        object from the same two constant buffers every step (unicorn.py:283); the gathered table is kept for as long
+        as those buffers are unchanged (same storage, same version counter)."""
         if self._shared_tables() or len(self) == 1:
-            return self._verts_uvs[0][self._faces_uvs[0]].contiguous(), True
+            vu, fu = self._verts_uvs, self._faces_uvs
+            if vu.requires_grad:
+                return vu[0][fu[0]].contiguous(), True
+            key = (vu.data_ptr(), vu._version, tuple(vu.shape[1:]), fu.data_ptr(), fu._version, tuple(fu.shape[1:]),
+                   str(vu.device))
+            hit = TexturesUV._uv_cache.get(key)
+            if hit is None:
+                if len(TexturesUV._uv_cache) > 16:
+                    TexturesUV._uv_cache.clear()
+                # the entry keeps vu / fu alive, so their addresses cannot be handed to other tensors meanwhile
+                hit = TexturesUV._uv_cache[key] = (vu[0][fu[0]].contiguous(), vu, fu)
+            return hit[0], True
         idx = self._faces_uvs  # (N,F,3)
         N, F = idx.shape[:2]
         out = torch.gather(self._verts_uvs, 1, idx.reshape(N, F * 3, 1).expand(-1, -1, 2)).view(N * F, 3, 2)
