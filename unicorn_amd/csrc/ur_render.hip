@@ -42,21 +42,60 @@ int check_launch(const char* what) {
   return UR_OK;
 }
 
+// Wave-wide inclusive scans on the VALU's data-parallel-primitive lanes (row shifts inside a 16-lane row, then the
+// two row broadcasts): six VALU operations, where a __shfl_up ladder is six dependent trips through the LDS crossbar.
+// `ident` is the operation's neutral element (what a lane combines with when it has no source lane).
+#define UR_SCAN_STEP(CTRL, ROWMASK) v = op(v, __builtin_amdgcn_update_dpp(ident, v, CTRL, ROWMASK, 0xf, false))
+template <class Op> __device__ __forceinline__ int wave_scan(int v, int ident, Op op) {
+  UR_SCAN_STEP(0x111, 0xf);  // row_shr:1
+  UR_SCAN_STEP(0x112, 0xf);  // row_shr:2
+  UR_SCAN_STEP(0x114, 0xf);  // row_shr:4
+  UR_SCAN_STEP(0x118, 0xf);  // row_shr:8
+  UR_SCAN_STEP(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+  UR_SCAN_STEP(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+#undef UR_SCAN_STEP
+__device__ __forceinline__ int wave_scan_add(int v) {
+  return wave_scan(v, 0, [](int a, int b) { return a + b; });
+}
+__device__ __forceinline__ int wave_scan_max(int v) {  // v >= 0
+  return wave_scan(v, 0, [](int a, int b) { return max(a, b); });
+}
+// maximum over the wave of non-negative ints, in every lane
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_scan_max(v), 63); }
+__device__ __forceinline__ float wave_fmin(float v) {
+  const int r = wave_scan(__float_as_int(v), __float_as_int(__builtin_inff()),
+                          [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); });
+  return __int_as_float(__builtin_amdgcn_readlane(r, 63));
+}
+__device__ __forceinline__ float wave_fmax(float v) {
+  const int r = wave_scan(__float_as_int(v), __float_as_int(-__builtin_inff()),
+                          [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); });
+  return __int_as_float(__builtin_amdgcn_readlane(r, 63));
+}
+
+constexpr int kPrepBins = 4096;  // bins per image the face-prep kernel counts in LDS (16 KB); beyond: global atomics
+
 // ------------------------------------------------------------------------------------------------------------------
 // face records
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv, int64_t NF, float r, int cull,
                                                    float4* __restrict__ bbox, float4* __restrict__ rec,
-                                                   float* __restrict__ fz) {
+                                                   float* __restrict__ fz, const int64_t* __restrict__ first, int N,
+                                                   int H, int W, int* __restrict__ binload) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= NF) return;
+  const bool live = i < NF;
+  bool culled = true;
+  float xlo = 0.0f, xhi = 0.0f, ylo = 0.0f, yhi = 0.0f;
+  if (live) {
   const float* p = fv + i * 9;
   const float v0x = p[0], v0y = p[1], z0 = p[2], v1x = p[3], v1y = p[4], z1 = p[5], v2x = p[6], v2y = p[7], z2 = p[8];
   const float zmax = max_s(max_s(z0, z1), z2);
   const float face_area = (v0x - v1x) * (v2y - v1y) - (v0y - v1y) * (v2x - v1x);  // edge(v0; v1, v2)
-  const bool culled = (zmax < kEps) || (face_area <= kEps && face_area >= -kEps) || (cull && face_area < 0.0f);
-  float xlo = min_s(min_s(v0x, v1x), v2x) - r, xhi = max_s(max_s(v0x, v1x), v2x) + r;
-  float ylo = min_s(min_s(v0y, v1y), v2y) - r, yhi = max_s(max_s(v0y, v1y), v2y) + r;
+  culled = (zmax < kEps) || (face_area <= kEps && face_area >= -kEps) || (cull && face_area < 0.0f);
+  xlo = min_s(min_s(v0x, v1x), v2x) - r; xhi = max_s(max_s(v0x, v1x), v2x) + r;
+  ylo = min_s(min_s(v0y, v1y), v2y) - r; yhi = max_s(max_s(v0y, v1y), v2y) + r;
   if (culled) { xlo = __builtin_inff(); xhi = -__builtin_inff(); }
   bbox[i] = make_float4(xlo, xhi, ylo, yhi);
   fz[i] = min_s(min_s(z0, z1), z2);
@@ -69,6 +108,88 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
   rec[5 * i + 2] = make_float4(z2, denom, 1.0f / denom, l01);
   rec[5 * i + 3] = make_float4(l02, l12, 1.0f / l01, 1.0f / l02);
   rec[5 * i + 4] = make_float4(1.0f / l12, d12x, d12y, min_s(min_s(z0, z1), z2));
+  }
+  // ---- load estimate for the workgroup schedule: +1 on every 16x16 bin the expanded box overlaps (a pixel of slack
+  //      either way -- this only orders the work, it decides nothing).  The workgroup first counts in LDS for the
+  //      mesh of its first face (consecutive faces nearly always share the mesh), then flushes the non-zero bins.
+  if (!binload) return;
+  const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nbins = nbx * nby;
+  __shared__ int s_load[kPrepBins];
+  __shared__ int s_mesh;
+  const bool use_lds = nbins <= kPrepBins;
+  if (use_lds) {
+    for (int j = threadIdx.x; j < nbins; j += 256) s_load[j] = 0;
+    if (threadIdx.x == 0) {
+      const int64_t i0 = (int64_t)blockIdx.x * blockDim.x;
+      int lo = 0, hi = N - 1;  // mesh of face i0: last n with first[n] <= i0
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= i0) lo = mid; else hi = mid - 1;
+      }
+      s_mesh = lo;
+    }
+    __syncthreads();
+  }
+  if (live && !culled) {
+    int lo = 0, hi = N - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (first[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const float rx = (W > H) ? 2.0f * (float)W / (float)H : 2.0f, ry = (H > W) ? 2.0f * (float)H / (float)W : 2.0f;
+    // column c has x = rx/2 - rx (c + 0.5) / W  (+X left), row likewise
+    const int c0 = max(0, (int)floorf((0.5f * rx - xhi) * (float)W / rx - 0.5f) - 1);
+    const int c1 = min(W - 1, (int)ceilf((0.5f * rx - xlo) * (float)W / rx - 0.5f) + 1);
+    const int r0 = max(0, (int)floorf((0.5f * ry - yhi) * (float)H / ry - 0.5f) - 1);
+    const int r1 = min(H - 1, (int)ceilf((0.5f * ry - ylo) * (float)H / ry - 0.5f) + 1);
+    const bool local = use_lds && lo == s_mesh;
+    for (int by = r0 >> 4; by <= (r1 >> 4); ++by)
+      for (int bx = c0 >> 4; bx <= (c1 >> 4); ++bx) {
+        if (local) atomicAdd(&s_load[by * nbx + bx], 1);
+        else atomicAdd(&binload[(int64_t)lo * nbins + by * nbx + bx], 1);
+      }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < nbins; j += 256) {
+      const int v = s_load[j];
+      if (v) atomicAdd(&binload[(int64_t)s_mesh * nbins + j], v);
+    }
+  }
+}
+
+// Workgroup schedule: bins sorted by descending load estimate (counting sort over 256 load classes, one workgroup).
+// The long-running bins -- silhouettes, where many faces pile up -- then start first and the cheap ones fill the gaps
+// at the end, instead of a late heavy bin stretching the kernel.  Any permutation gives the same results.
+__global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binload, int n_bins, int* __restrict__ order) {
+  __shared__ int s_hist[256];
+  __shared__ int s_max;
+  const int tid = threadIdx.x;
+  if (tid < 256) s_hist[tid] = 0;
+  if (tid == 0) s_max = 1;
+  __syncthreads();
+  int mx = 1;
+  for (int i = tid; i < n_bins; i += 1024) mx = max(mx, binload[i]);
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  const int top = s_max;
+  auto cls = [&](int v) { return 255 - (int)(((int64_t)v * 255) / top); };  // heaviest -> class 0
+  for (int i = tid; i < n_bins; i += 1024) atomicAdd(&s_hist[cls(binload[i])], 1);
+  __syncthreads();
+  {  // exclusive prefix over the 256 classes: scan inside each of the first four waves, then add the waves before
+    __shared__ int s_wsum[4];
+    const int h = tid < 256 ? s_hist[tid] : 0;
+    const int incl = wave_scan_add(h);
+    if (tid < 256 && (tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 256) {
+      int off = 0;
+      for (int w = 0; w < (tid >> 6); ++w) off += s_wsum[w];
+      s_hist[tid] = off + incl - h;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n_bins; i += 1024) order[atomicAdd(&s_hist[cls(binload[i])], 1)] = i;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -85,6 +206,7 @@ struct RasterParams {
   int clip;
   int nbx, nby;  // bins per row / column
   int cap;       // K-list slots per lane held in LDS
+  const int* order;  // workgroup -> (mesh * bins + bin), heaviest bins first
   unsigned long long* tim;  // DEV: per-block timestamps
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
   // outputs (fragments)
@@ -134,45 +256,6 @@ __host__ __device__ inline int64_t layer_counts_offset(int N, int nbx, int nby, 
   return (int64_t)N * nbx * nby * 4 * K * 6 * 64;
 }
 
-// r-th index of 0..n-1 counted from the centre outwards: c, c-1, c+1, c-2, ...
-__device__ __forceinline__ int centre_out(int r, int n) {
-  const int c = n >> 1, d = (r + 1) >> 1;
-  return (r & 1) ? c - d : c + d;
-}
-
-// Wave-wide inclusive scans on the VALU's data-parallel-primitive lanes (row shifts inside a 16-lane row, then the
-// two row broadcasts): six VALU operations, where a __shfl_up ladder is six dependent trips through the LDS crossbar.
-// `ident` is the operation's neutral element (what a lane combines with when it has no source lane).
-#define UR_SCAN_STEP(CTRL, ROWMASK) v = op(v, __builtin_amdgcn_update_dpp(ident, v, CTRL, ROWMASK, 0xf, false))
-template <class Op> __device__ __forceinline__ int wave_scan(int v, int ident, Op op) {
-  UR_SCAN_STEP(0x111, 0xf);  // row_shr:1
-  UR_SCAN_STEP(0x112, 0xf);  // row_shr:2
-  UR_SCAN_STEP(0x114, 0xf);  // row_shr:4
-  UR_SCAN_STEP(0x118, 0xf);  // row_shr:8
-  UR_SCAN_STEP(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
-  UR_SCAN_STEP(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
-  return v;
-}
-#undef UR_SCAN_STEP
-__device__ __forceinline__ int wave_scan_add(int v) {
-  return wave_scan(v, 0, [](int a, int b) { return a + b; });
-}
-__device__ __forceinline__ int wave_scan_max(int v) {  // v >= 0
-  return wave_scan(v, 0, [](int a, int b) { return max(a, b); });
-}
-// maximum over the wave of non-negative ints, in every lane
-__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_scan_max(v), 63); }
-__device__ __forceinline__ float wave_fmin(float v) {
-  const int r = wave_scan(__float_as_int(v), __float_as_int(__builtin_inff()),
-                          [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); });
-  return __int_as_float(__builtin_amdgcn_readlane(r, 63));
-}
-__device__ __forceinline__ float wave_fmax(float v) {
-  const int r = wave_scan(__float_as_int(v), __float_as_int(-__builtin_inff()),
-                          [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); });
-  return __int_as_float(__builtin_amdgcn_readlane(r, 63));
-}
-
 __device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float xc_hi, float yc_lo, float yc_hi) {
   // bb = xlo xhi ylo yhi ; reject iff the whole centre interval is on one side of the box
   return !(xc_hi < bb.x || xc_lo > bb.y || yc_hi < bb.z || yc_lo > bb.w);
@@ -215,11 +298,11 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(s_rec + 2 * kSub * 5);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // workgroup order: bins from the image centre outwards (rows, then columns), image index fastest -- the bins that
-  // hold the object, the long-running ones, start first and the empty border bins fill the gaps at the end
-  const int n = blockIdx.x % P.N;
-  const int b = blockIdx.x / P.N;
-  const int by = centre_out(b / P.nbx, P.nby), bx = centre_out(b % P.nbx, P.nbx);
+  // workgroup schedule: heaviest bins first (k_bin_order)
+  const int item = P.order[blockIdx.x];
+  const int n = item / (P.nbx * P.nby);
+  const int b = item - n * (P.nbx * P.nby);
+  const int by = b / P.nbx, bx = b - by * P.nbx;
   const int H = P.H, W = P.W, K = P.K;
 
   // bin extents in pixel-centre NDC (columns x0..x1, rows y0..y1, clamped to the image)
@@ -833,23 +916,37 @@ template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
   return check_launch("k_raster");
 }
 
-// workspace = [bbox: NF float4][records: NF x 5 float4][nearest depth: NF float, padded to 16 B][K-list spill]
-int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, int N, int H, int W, int K, void* ws,
-               size_t ws_bytes, hipStream_t st, RasterParams& P) {
+// workspace = [bbox: NF float4][records: NF x 5 float4][nearest depth: NF float, padded to 16 B]
+//             [bin loads: N * bins int, padded to 16 B][schedule: N * bins int, padded][K-list spill]
+size_t sched_ints(int N, int H, int W) { return (((size_t)N * ((H + 15) / 16) * ((W + 15) / 16)) + 3) / 4 * 4; }
+
+const int* sched_order(const void* ws, int64_t NF, int N, int H, int W) {
+  const float* fz = reinterpret_cast<const float*>(reinterpret_cast<const float4*>(ws) + 6 * NF);
+  return reinterpret_cast<const int*>(fz + ((NF + 3) / 4) * 4) + sched_ints(N, H, W);
+}
+
+int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const int64_t* first, int N, int H, int W,
+               int K, void* ws, size_t ws_bytes, hipStream_t st, RasterParams& P) {
   const size_t need = ur_workspace_bytes(NF, N, H, W, K);
   if (ws_bytes < need) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
   float4* bbox = reinterpret_cast<float4*>(ws);
   float4* rec = bbox + NF;
   float* fz = reinterpret_cast<float*>(rec + 5 * NF);
-  P.bbox = bbox; P.rec = rec; P.fz = fz;
-  P.spill = reinterpret_cast<unsigned long long*>(fz + ((NF + 3) / 4) * 4);
+  int* binload = reinterpret_cast<int*>(fz + ((NF + 3) / 4) * 4);
+  int* order = binload + sched_ints(N, H, W);
+  const int n_bins = N * ((H + 15) / 16) * ((W + 15) / 16);
+  P.bbox = bbox; P.rec = rec; P.fz = fz; P.order = order;
+  P.spill = reinterpret_cast<unsigned long long*>(order + sched_ints(N, H, W));
+  if (hipMemsetAsync(binload, 0, (size_t)n_bins * 4, st) != hipSuccess) return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
   if (NF > 0) {
     hipLaunchKernelGGL(k_face_prep, dim3((unsigned)((NF + 255) / 256)), dim3(256), 0, st, face_verts, NF,
-                       sqrtf(blur), cull, bbox, rec, fz);
-    return check_launch("k_face_prep");
+                       sqrtf(blur), cull, bbox, rec, fz, first, N, H, W, binload);
+    int rc = check_launch("k_face_prep");
+    if (rc) return rc;
   }
-  return UR_OK;
+  hipLaunchKernelGGL(k_bin_order, dim3(1), dim3(1024), 0, st, binload, n_bins, order);
+  return check_launch("k_bin_order");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1025,11 +1122,12 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   __shared__ int s_pre_all[4 * 80];  // per wave: 64 item prefixes, then 64 byte marks
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = P.H, W = P.W, K = P.K;
-  // same workgroup order and pixel ownership as the forward: bins centre-out with the image index fastest; wave w
-  // holds every second column / row of the bin from (w & 1, w >> 1)
-  const int n = blockIdx.x % P.N;
-  const int b = blockIdx.x / P.N;
-  const int by = centre_out(b / P.nbx, P.nby), bx = centre_out(b % P.nbx, P.nbx);
+  // same workgroup schedule and pixel ownership as the forward: heaviest bins first; wave w holds every second
+  // column / row of the bin from (w & 1, w >> 1)
+  const int item = P.order[blockIdx.x];
+  const int n = item / (P.nbx * P.nby);
+  const int b = item - n * (P.nbx * P.nby);
+  const int by = b / P.nbx, bx = b - by * P.nbx;
   const int tx0 = bx * 16 + (wave & 1), ty0 = by * 16 + (wave >> 1);
   const bool tile_live = (tx0 < W) && (ty0 < H);
   const int x = tx0 + 2 * (lane & 7), y = ty0 + 2 * (lane >> 3);
@@ -1567,10 +1665,11 @@ void ur_dev_set_timing(void* p) { g_dev_tim = (unsigned long long*)p; }
 int ur_abi_version(void) { return 1; }
 
 size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
-  // bbox (16 B) + record (80 B) + nearest depth (4 B) per face, then the spill area of the per-pixel K-lists (only when K exceeds what
+  // bbox (16 B) + record (80 B) + nearest depth (4 B) per face, the workgroup schedule, then the spill area of the per-pixel K-lists (only when K exceeds what
   // LDS holds)
   const size_t nf = (size_t)(total_faces < 1 ? 1 : total_faces);
-  return nf * 96 + ((nf + 3) / 4) * 16 + raster_spill_bytes(N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
+  return nf * 96 + ((nf + 3) / 4) * 16 + 2 * sched_ints(N < 0 ? 0 : N, H, W) * 4 +
+         raster_spill_bytes(N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
 }
 
 int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
@@ -1627,8 +1726,8 @@ int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face,
   if (N == 0) return UR_OK;
   hipStream_t st = (hipStream_t)stream;
   RasterParams P{};
-  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, N, H, W, K, workspace, workspace_bytes, st,
-                      P);
+  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, mesh_first_face, N, H, W, K, workspace,
+                      workspace_bytes, st, P);
   if (rc) return rc;
   P.first = mesh_first_face; P.nfaces = mesh_num_faces;
   P.N = N; P.H = H; P.W = W; P.K = K; P.blur = blur_radius; P.clip = clip_barycentric_coords;
@@ -1645,8 +1744,8 @@ int ur_tile_faces(const float* face_verts, const int64_t* mesh_first_face, const
   if (N == 0) return UR_OK;
   hipStream_t st = (hipStream_t)stream;
   RasterParams P{};
-  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, N, H, W, 1, workspace, workspace_bytes, st,
-                      P);
+  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, mesh_first_face, N, H, W, 1, workspace,
+                      workspace_bytes, st, P);
   if (rc) return rc;
   P.first = mesh_first_face; P.nfaces = mesh_num_faces;
   P.N = N; P.H = H; P.W = W; P.K = 1; P.blur = blur_radius; P.clip = 0;
@@ -1749,7 +1848,8 @@ int ur_render_layered_forward(const float* face_verts, const int64_t* mesh_first
   if (rc) return rc;
   if (N == 0) return UR_OK;
   hipStream_t st = (hipStream_t)stream;
-  rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, N, H, W, K, workspace, workspace_bytes, st, P);
+  rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, mesh_first_face, N, H, W, K, workspace,
+                  workspace_bytes, st, P);
   if (rc) return rc;
   P.image = image; P.layers = layers;
   return launch_raster<2>(P, st);
@@ -1765,7 +1865,7 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   if (!grad_image || !layers || !workspace || !scratch) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (scratch_bytes < ur_backward_scratch_bytes(N, H, W, K)) return fail(UR_ERR_WORKSPACE, "scratch too small");
   if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
-  if (workspace_bytes < ur_workspace_bytes(total_faces, 0, H, W, K)) return fail(UR_ERR_WORKSPACE, "workspace too small");
+  if (workspace_bytes < ur_workspace_bytes(total_faces, N, H, W, K)) return fail(UR_ERR_WORKSPACE, "workspace too small");
   RasterParams P{};
   int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
                               face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
@@ -1773,6 +1873,7 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   if (N == 0 || (!grad_face_verts && !grad_maps)) return UR_OK;
   P.bbox = reinterpret_cast<const float4*>(workspace);
   P.rec = P.bbox + total_faces;
+  P.order = sched_order(workspace, total_faces, N, H, W);
   P.layers = const_cast<int32_t*>(layers);
   P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
   P.scratch = reinterpret_cast<float*>(scratch);
