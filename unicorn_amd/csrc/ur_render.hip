@@ -276,6 +276,28 @@ struct KeyList {
   __device__ __forceinline__ void put(int i, unsigned long long v) const {
     if (i < cap) lds[(size_t)i * 64] = v; else spill[(size_t)(i - cap) * 64] = v;
   }
+  // Keep, in order, the entries <= bound of this lane's first n entries (lanes with !need keep everything and
+  // return n); mx = the largest n among the lanes that need it (wave-uniform).  The spilled part is read eight
+  // entries at a time so that the global loads overlap instead of forming one dependent chain.
+  __device__ __forceinline__ int compact(bool need, int n, int mx, unsigned long long bound) const {
+    if (!need) n = 0;  // nothing to do in the loops below
+    int j = 0;
+    const int lds_n = mx < cap ? mx : cap;
+    for (int i = 0; i < lds_n; ++i)
+      if (i < n) {
+        const unsigned long long kk = lds[(size_t)i * 64];
+        if (kk <= bound) { put(j, kk); ++j; }
+      }
+    for (int i0 = cap; i0 < mx; i0 += 8) {
+      unsigned long long t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = (i0 + q < n) ? spill[(size_t)(i0 + q - cap) * 64] : ~0ull;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i0 + q < n && t[q] <= bound) { put(j, t[q]); ++j; }
+    }
+    return j;
+  }
 };
 
 // MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
@@ -592,12 +614,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 const unsigned long long hk = s_hide[lane];
                 const bool need = (hk != last_hk) && c2 > 0;
                 const int mx = __builtin_amdgcn_readfirstlane(wave_max(need ? c2 : 0));
-                int j = 0;
-                for (int i = 0; i < mx; ++i)
-                  if (need && i < c2) {
-                    const unsigned long long kk = keys.get(i);
-                    if (kk <= hk) { keys.put(j, kk); ++j; }
-                  }
+                const int j = keys.compact(need, c2, mx, hk);
                 if (need) { c2 = j; s_cnt[lane] = c2; }
                 last_hk = hk;
                 any_stale = false;
@@ -710,12 +727,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     int n_rel = cnt;
     if (__any(hide_key != ~0ull && cnt > 0)) {
       const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(hide_key != ~0ull ? cnt : 0));
-      int j = 0;
-      for (int i = 0; i < maxcnt; ++i)
-        if (i < cnt && hide_key != ~0ull) {
-          const unsigned long long kk = keys.get(i);
-          if (kk <= hide_key) { keys.put(j, kk); ++j; }
-        }
+      const int j = keys.compact(hide_key != ~0ull, cnt, maxcnt, hide_key);
       if (hide_key != ~0ull) n_rel = j;
     }
     if (!pix_live) n_rel = 0;
