@@ -1131,7 +1131,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   __shared__ double s_fval[kFaceSlots * 6];
   __shared__ int s_ttag[kTexSlots];
   __shared__ double s_tval[kTexSlots * 3];
-  __shared__ int s_pre_all[4 * 80];  // per wave: 64 item prefixes, then 64 byte marks
+  __shared__ int s_pre_all[4 * 136];  // per wave: 64 compacted pixels, then their 65 + pad first-item indices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = P.H, W = P.W, K = P.K;
   // same workgroup schedule and pixel ownership as the forward: heaviest bins first; wave w holds every second
@@ -1203,24 +1203,43 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     const int incl = wave_scan_add(m);
     const int pre = incl - m;
     const int total = __builtin_amdgcn_readlane(incl, 63);
-    int* s_pre = s_pre_all + wave * 80;
-    unsigned char* marks = reinterpret_cast<unsigned char*>(s_pre + 64);
-    s_pre[lane] = pre;
+    // Lane L takes the items [L nb, (L+1) nb) of the tile's pixel-major item list, nb = batches: in any one batch the
+    // 64 lanes then sit in 64 different neighbourhoods of the tile, so few of them meet on the same face / texel --
+    // an LDS atomic costs ~12 clocks per extra lane on its address.  The pixels that have layers are compacted into
+    // (pixel, count) / first-item arrays; a lane finds its first item by binary search and then just walks on.
+    int* s_own = s_pre_all + wave * 136;   // 64 entries: pixel | count << 8
+    int* s_opre = s_own + 64;              // 65 entries: first item of the r-th pixel with layers, then sentinels
+    const unsigned long long om = __ballot(m > 0);
+    const int nown = __popcll(om);
+    if (m > 0) {
+      const int rank = __popcll(om & ((1ull << lane) - 1ull));
+      s_own[rank] = lane | (m << 8);
+      s_opre[rank] = pre;
+    }
+    if (lane >= nown) s_opre[lane] = 0x7fffffff;
+    if (lane == 0) s_opre[64] = 0x7fffffff;
+    const int nbatch = (total + 63) >> 6;
+    const int item0 = lane * nbatch;
+    int rr = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1)
+      if (s_opre[rr + step] <= item0) rr += step;
+    int k = item0 - s_opre[rr];
+    int ow = s_own[rr];
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
     const bool clip = P.clip != 0;
-    for (int base = 0; base < total; base += 64) {
-      const int item = base + lane;
-      // owner of item: pixels whose first item falls inside the batch mark that slot, slot 0 takes the pixel that
-      // holds item `base`, a running maximum spreads the marks to the right
-      marks[lane] = 0;
-      const int l0 = 63 - __builtin_clzll(__ballot(m > 0 && pre <= base));
-      if (m > 0 && pre > base && pre < base + 64) marks[pre - base] = (unsigned char)(lane + 1);
-      int l = wave_scan_max(lane == 0 ? l0 + 1 : (int)marks[lane]) - 1;
+    for (int bi = 0; bi < nbatch; ++bi, ++k) {
+      if (k >= (ow >> 8)) {  // on to the next pixel that has layers
+        rr = min(rr + 1, 63);
+        ow = s_own[rr];
+        k = 0;
+      }
+      const int item = item0 + bi;
+      int l = ow & 255;
       if (item >= total) l = lane;
       // cotangent of the owner pixel (all lanes take part in the shuffles)
       const float q0 = __shfl(g0, l, 64), q1 = __shfl(g1, l, 64), q2 = __shfl(g2, l, 64);
       if (item >= total) continue;
-      const int k = item - s_pre[l];
       const int32_t* le = lay_tile + (int64_t)k * 6 * 64 + l;
       const int fid = le[0];
       const float a = __int_as_float(le[128]);
