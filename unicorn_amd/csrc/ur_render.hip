@@ -64,6 +64,11 @@ __device__ __forceinline__ int wave_scan_max(int v) {  // v >= 0
 }
 // maximum over the wave of non-negative ints, in every lane
 __device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_scan_max(v), 63); }
+// sum over the wave (valid in lane 63; summation order fixed by the scan network: deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+  return __int_as_float(wave_scan(__float_as_int(v), 0, [](int a, int b) {
+    return __float_as_int(__int_as_float(a) + __int_as_float(b)); }));
+}
 __device__ __forceinline__ float wave_fmin(float v) {
   const int r = wave_scan(__float_as_int(v), __float_as_int(__builtin_inff()),
                           [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); });
@@ -163,21 +168,34 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
 // at the end, instead of a late heavy bin stretching the kernel.  Any permutation gives the same results.
 __global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binload, int n_bins, int* __restrict__ order) {
   __shared__ int s_hist[256];
+  __shared__ int s_wsum[4];
   __shared__ int s_max;
   const int tid = threadIdx.x;
   if (tid < 256) s_hist[tid] = 0;
   if (tid == 0) s_max = 1;
+  // the first four loads of every thread stay in registers for the three passes (covers 4096 bins)
+  int v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = (tid + q * 1024 < n_bins) ? binload[tid + q * 1024] : 0;
+  auto each = [&](auto fn) {  // fn(load, bin index) over this thread's bins
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (tid + q * 1024 < n_bins) fn(v[q], tid + q * 1024);
+    for (int i = tid + 4096; i < n_bins; i += 1024) fn(binload[i], i);
+  };
   __syncthreads();
   int mx = 1;
-  for (int i = tid; i < n_bins; i += 1024) mx = max(mx, binload[i]);
-  atomicMax(&s_max, mx);
+  each([&](int x, int) { mx = max(mx, x); });
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) atomicMax(&s_max, mx);
   __syncthreads();
-  const int top = s_max;
-  auto cls = [&](int v) { return 255 - (int)(((int64_t)v * 255) / top); };  // heaviest -> class 0
-  for (int i = tid; i < n_bins; i += 1024) atomicAdd(&s_hist[cls(binload[i])], 1);
+  const float scale = 127.0f / (float)s_max;
+  // classes 0..127: loaded bins, heaviest first; classes 128..255: the empty bins, spread by index so that they do
+  // not all queue on one LDS counter
+  auto cls = [&](int x, int i) { return x <= 0 ? 128 + (i & 127) : 127 - min(127, (int)((float)x * scale)); };
+  each([&](int x, int i) { atomicAdd(&s_hist[cls(x, i)], 1); });
   __syncthreads();
   {  // exclusive prefix over the 256 classes: scan inside each of the first four waves, then add the waves before
-    __shared__ int s_wsum[4];
     const int h = tid < 256 ? s_hist[tid] : 0;
     const int incl = wave_scan_add(h);
     if (tid < 256 && (tid & 63) == 63) s_wsum[tid >> 6] = incl;
@@ -189,7 +207,7 @@ __global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binl
     }
   }
   __syncthreads();
-  for (int i = tid; i < n_bins; i += 1024) order[atomicAdd(&s_hist[cls(binload[i])], 1)] = i;
+  each([&](int x, int i) { order[atomicAdd(&s_hist[cls(x, i)], 1)] = i; });
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1634,10 +1652,8 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
   if (!gR && !gT) return;
 #pragma unroll
   for (int q = 0; q < 12; ++q) {
-    float v = s[q];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((tid & 63) == 0) part[(tid >> 6) * 12 + q] = v;
+    const float v = wave_sum(s[q]);
+    if ((tid & 63) == 63) part[(tid >> 6) * 12 + q] = v;
   }
   __syncthreads();
   if (tid < 12) {
