@@ -40,6 +40,20 @@ extern "C" {
 const char* ur_last_error(void);
 int ur_abi_version(void);
 
+/*
+ * Opt-in kernel timing (no counterpart in the reference; for bench.py's roofline leg and for tuning).  Between
+ * ur_profile_begin and ur_profile_end every launch of the two dominant kernels -- the fused forward rasterizer
+ * (UR_PROFILE_RASTER_FWD) and the fused backward (UR_PROFILE_RENDER_BWD) -- is bracketed by a pair of HIP events
+ * recorded on the stream the kernel is launched on, up to max_launches launches; ur_profile_end waits for them and
+ * returns the durations in milliseconds (host arrays) in launch order.  Process-wide state, not for use under graph
+ * capture; the rest of the library stays stateless.
+ */
+#define UR_PROFILE_OTHER 0
+#define UR_PROFILE_RASTER_FWD 1
+#define UR_PROFILE_RENDER_BWD 2
+int ur_profile_begin(int max_launches);
+int ur_profile_end(float* ms, int* kinds, int capacity, int* count);
+
 /* Bytes of device workspace the raster / render entry points need: per-face records for `total_faces` packed faces
  * plus, when faces_per_pixel K exceeds what the LDS holds per pixel, a spill area for the per-pixel top-K lists. */
 size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K);

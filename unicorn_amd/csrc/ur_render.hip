@@ -17,6 +17,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <atomic>
+#include <vector>
+
 #include "../../include/unicorn_render.h"
 #include "ur_device.h"
 
@@ -35,6 +39,32 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+
+// ---- opt-in kernel timing (ur_profile_begin / ur_profile_end): HIP events recorded on the launch stream right around
+// the two dominant kernels.  Process-wide (the autograd engine runs the backward on another thread than the forward).
+struct ProfState {
+  std::vector<hipEvent_t> ev;   // 2 per slot: start, stop
+  std::vector<int> kind;        // UR_PROFILE_RASTER_FWD / UR_PROFILE_RENDER_BWD
+  std::atomic<int> next{0};
+  std::atomic<bool> on{false};
+};
+ProfState g_prof;
+
+struct ProfScope {  // records the slot's events around a kernel launch when profiling is on
+  hipStream_t st;
+  int slot = -1;
+  ProfScope(int kind, hipStream_t s) : st(s) {
+    if (!g_prof.on.load(std::memory_order_acquire)) return;
+    const int i = g_prof.next.fetch_add(1);
+    if (i >= (int)g_prof.kind.size()) return;
+    slot = i;
+    g_prof.kind[i] = kind;
+    (void)hipEventRecord(g_prof.ev[2 * i], st);
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  }
+};
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -225,7 +255,6 @@ struct RasterParams {
   int nbx, nby;  // bins per row / column
   int cap;       // K-list slots per lane held in LDS
   const int* order;  // workgroup -> (mesh * bins + bin), heaviest bins first
-  unsigned long long* tim;  // DEV: per-block timestamps
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
   // outputs (fragments)
   int32_t* p2f;
@@ -409,9 +438,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 
   const int64_t f0 = P.first[n];
   const int nf = (int)P.nfaces[n];
-  unsigned long long* wt = P.tim ? P.tim + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
-  if (MODE == 2 && wt && lane == 0) { wt[0] = wall_clock64(); }
-  unsigned long long t_scan = 0, d_bar = 0, d_setup = 0, n_batch = 0, n_pairs = 0, n_faces = 0, d_comp = 0, n_comp = 0;
 
   for (int rbase = 0; rbase < nf; rbase += kBinCap) {
     // ---- coarse: the round's faces (up to 2048) are split evenly over the waves, wave w scans a contiguous range
@@ -493,7 +519,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       }
     }
     __syncthreads();
-    if (MODE == 2 && P.tim) { t_scan = wall_clock64(); if (rbase == 0 && lane == 0) wt[15] = t_scan; }
     if (list_n == 0) continue;
 
     // ---- fine: 64 bin faces at a time; their bboxes / records are staged in LDS by the whole workgroup (next step's
@@ -562,7 +587,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 
     for (int c = 0; c < nsub; ++c) {
       if (c + 1 < nsub) stage_load(c + 1);
-      const unsigned long long t_c0 = P.tim ? wall_clock64() : 0;
       if (tile_live) {
         const int cntc = min(kSub, list_n - c * kSub);
         const float4* bbs = s_bb + (c & 1) * kSub;
@@ -619,14 +643,11 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
             const unsigned cinfo = s_finfo[lane];
             const int lim = min(P.cap, K);
             int r0 = 0;
-            if (P.tim) { d_setup += wall_clock64() - t_c0; n_pairs += total_pairs; n_faces += nfp; }
             while (r0 < nfp) {
               // how many faces can go the pair way: each adds at most one entry to any pixel's list, and no list
               // may pass K (there the exact keep-the-K-smallest rule takes over, lane = pixel)
               int c2 = s_cnt[lane];
               int cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
-              const unsigned long long t_k0 = P.tim ? wall_clock64() : 0;
-              const bool do_comp = any_stale && cmax + (nfp - r0) > lim;
               if (any_stale && cmax + (nfp - r0) > lim) {
                 // compact the lists whose hide key moved: drop what the nearest hiding hit made irrelevant
                 const unsigned long long hk = s_hide[lane];
@@ -638,7 +659,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 any_stale = false;
                 cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
               }
-              if (P.tim && do_comp) { d_comp += wall_clock64() - t_k0; ++n_comp; }
               const int room = K - cmax;
               if (room < min(nfp - r0, 4)) {
                 const int r1 = min(nfp, r0 + 8);
@@ -659,10 +679,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
               const int pbeg = __builtin_amdgcn_readlane(cpre, r0), pend = __builtin_amdgcn_readlane(cend, r1 - 1);
               bool improved = false;
               for (int pb = pbeg; pb < pend; pb += 64) {
-                ++n_batch;
-                const bool stamp = P.tim && n_batch == 3;
-                unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
-                if (stamp) ts0 = wall_clock64();
                 const int pidx = pb + lane;
                 const bool act = pidx < pend;
                 // which face does pair pidx belong to?  The faces that start inside the batch mark their first
@@ -682,17 +698,14 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 const int src = (int)(info & 63u);
                 const int pl = act ? ((((int)((info >> 9) & 7u) + dy) << 3) | ((int)((info >> 6) & 7u) + dx)) : lane;
                 const float qx = __shfl(px, pl, 64), qy = __shfl(py, pl, 64);
-                if (stamp) { asm volatile("" :: "v"(qx), "v"(qy)); ts2 = wall_clock64(); }
                 if (act) {
                   const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
                                               rcs[src * 5 + 4]);
                   unsigned long long hk = s_hide[pl];
-                  if (stamp) { asm volatile("" :: "v"(fc.v0x), "v"(fc.zmin), "v"(hk)); ts3 = wall_clock64(); }
                   bool hit = true;
                   if (can_cull && hk != ~0ull) hit = !(fc.zmin * 0.9999f > __uint_as_float((unsigned)(hk >> 32)));
                   Eval ev;
                   if (hit) hit = eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
-                  if (stamp) { asm volatile("" :: "v"(ev.sd), "v"(ev.pz)); ts4 = wall_clock64(); }
                   if (hit) {
                     const bool hides = hides_rest(ev.sd, P.sigma, P.mode);
                     const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
@@ -712,12 +725,9 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           }
         }
       }
-      const unsigned long long t_c1 = P.tim ? wall_clock64() : 0;
       if (c + 1 < nsub) stage_write(c + 1);
       __syncthreads();
-      if (P.tim) d_bar += wall_clock64() - t_c1;
     }
-    if (MODE == 2 && wt && lane == 0) { wt[12] = nsub; wt[13] = list_n; }
   }
 
   if (MODE == 1) {
@@ -730,7 +740,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   if (!tile_live) return;
 
   if (MODE == 2) {
-    if (wt && lane == 0) { wt[2] = wall_clock64(); wt[8] = n_batch; wt[9] = n_pairs; wt[10] = d_bar; wt[11] = d_setup; wt[7] = n_faces; wt[3] = d_comp; wt[4] = n_comp; }
     // ---- fused shading.  (a) per pixel: drop the hits behind the nearest one that hides the rest, sort what is left
     //      front to back (in place; that hit, if any, comes last);  (b) the (pixel, layer) items of the whole tile
     //      are dealt out evenly over the 64 lanes -- any lane can evaluate any item -- so every lane stays busy
@@ -861,7 +870,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       img[2 * hw] = b + occ * 1.0f * P.bg[2];
       img[3 * hw] = 1.0f - occ;
     }
-    if (wt && lane == 0) { wt[5] = wall_clock64(); }
     return;
   }
 
@@ -926,9 +934,7 @@ size_t raster_spill_bytes(int N, int H, int W, int K) {
   return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
 }
 
-unsigned long long* g_dev_tim = nullptr;
 template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
-  P.tim = g_dev_tim;
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
   P.cap = (MODE == 1) ? 1 : raster_cap(P.K);
@@ -942,7 +948,10 @@ template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
   }
   const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
-  hipLaunchKernelGGL((k_raster<MODE>), dim3((unsigned)blocks), dim3(256), lds, st, P);
+  {
+    ProfScope prof(MODE == 2 ? UR_PROFILE_RASTER_FWD : UR_PROFILE_OTHER, st);
+    hipLaunchKernelGGL((k_raster<MODE>), dim3((unsigned)blocks), dim3(256), lds, st, P);
+  }
   return check_launch("k_raster");
 }
 
@@ -1168,12 +1177,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 2 * 64;         // [K][2][64]
   float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
 
-  unsigned long long* wt = P.tim ? P.tim + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
-  if (wt && lane == 0) wt[0] = wall_clock64();
   // this pixel's layer count (left by the forward)
   const int m = (tile_live && live) ? P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] : 0;
   const int maxm = __builtin_amdgcn_readfirstlane(wave_max(m));
-  if (wt && lane == 0) wt[1] = wall_clock64();
   if (!__syncthreads_or(maxm > 0)) return;  // nothing rendered in this bin
   for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
   for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0;
@@ -1215,7 +1221,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
         if (h0) sweep(k0, o0, a0, r0, gg0, b0);
       }
     }
-    if (wt && lane == 0) wt[2] = wall_clock64();
     // ---- (b) the tile's (pixel, layer) items dealt out evenly over the lanes: geometry is re-evaluated once per
     //      item, gradients go to the LDS tables
     const int incl = wave_scan_add(m);
@@ -1349,7 +1354,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     }
   }
 
-  if (wt && lane == 0) { wt[3] = wall_clock64(); wt[6] = (unsigned long long)maxm; }
   __syncthreads();
   if (P.gfv)
     for (int i = tid; i < kFaceSlots * 6; i += 256) {
@@ -1365,7 +1369,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       const float v = (float)s_tval[i];
       if (tag >= 0 && v != 0.0f) atomicAdd(gmap + (int64_t)tag * 3 + c, v);
     }
-  if (wt && lane == 0) wt[4] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1708,8 +1711,39 @@ int fill_shade_params(ShadeParams& P, const int32_t* p2f, const float* bary, con
 extern "C" {
 
 const char* ur_last_error(void) { return g_err; }
-void ur_dev_set_timing(void* p) { g_dev_tim = (unsigned long long*)p; }
-int ur_abi_version(void) { return 1; }
+int ur_abi_version(void) { return 2; }
+
+int ur_profile_begin(int max_launches) {
+  if (max_launches <= 0) return fail(UR_ERR_INVALID_ARG, "max_launches must be > 0");
+  if (g_prof.on.load()) return fail(UR_ERR_INVALID_ARG, "profiling already on");
+  g_prof.ev.assign((size_t)2 * max_launches, nullptr);
+  g_prof.kind.assign((size_t)max_launches, UR_PROFILE_OTHER);
+  for (auto& e : g_prof.ev)
+    if (hipEventCreate(&e) != hipSuccess) return fail(UR_ERR_LAUNCH, "hipEventCreate failed");
+  g_prof.next.store(0);
+  g_prof.on.store(true, std::memory_order_release);
+  return UR_OK;
+}
+
+int ur_profile_end(float* ms, int* kinds, int capacity, int* count) {
+  if (!g_prof.on.load()) return fail(UR_ERR_INVALID_ARG, "profiling is not on");
+  g_prof.on.store(false);
+  const int n = std::min(g_prof.next.load(), (int)g_prof.kind.size());
+  int out = 0;
+  for (int i = 0; i < n; ++i) {
+    float t = 0.0f;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+      continue;
+    if (out < capacity && ms && kinds) { ms[out] = t; kinds[out] = g_prof.kind[i]; }
+    ++out;
+  }
+  for (auto e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.kind.clear();
+  if (count) *count = out < capacity ? out : capacity;
+  return UR_OK;
+}
 
 size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
   // bbox (16 B) + record (80 B) + nearest depth (4 B) per face, the workgroup schedule, then the spill area of the per-pixel K-lists (only when K exceeds what
@@ -1928,8 +1962,10 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   P.nby = (H + 15) / 16;
   const int64_t blocks = (int64_t)N * P.nbx * P.nby;
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
-  P.tim = g_dev_tim;
-  hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+  {
+    ProfScope prof(UR_PROFILE_RENDER_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+  }
   return check_launch("k_render_bwd");
 }
 

@@ -22,6 +22,8 @@ _F3 = ctypes.c_float * 3
 _SIGNATURES = {
     "ur_last_error": (ctypes.c_char_p, []),
     "ur_abi_version": (_i, []),
+    "ur_profile_begin": (_i, [_i]),
+    "ur_profile_end": (_i, [_vp, _vp, _i, _vp]),
     "ur_workspace_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "ur_project_faces": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp]),
     "ur_project_faces_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -313,6 +315,24 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
             _ptr(gfv, None, True),
             _ptr(gmaps, None, True), _stream(maps)), "ur_render_layered_backward")
     return gfv, gmaps
+
+
+def profile_begin(max_launches):
+    """start bracketing the fused forward / backward kernels with HIP events on their launch stream"""
+    _check(lib().ur_profile_begin(int(max_launches)), "ur_profile_begin")
+
+
+def profile_end(max_launches):
+    """-> {"k_raster<2>": [ms, ...], "k_render_bwd": [ms, ...]} for the launches since profile_begin"""
+    ms = (ctypes.c_float * max_launches)()
+    kinds = (ctypes.c_int * max_launches)()
+    count = ctypes.c_int(0)
+    _check(lib().ur_profile_end(ms, kinds, int(max_launches), ctypes.byref(count)), "ur_profile_end")
+    names = {1: "k_raster<2>", 2: "k_render_bwd"}
+    out = {}
+    for i in range(count.value):
+        out.setdefault(names.get(kinds[i], "other"), []).append(float(ms[i]))
+    return out
 
 
 def selftest_division(n, seed=0, device="cuda"):
