@@ -14,7 +14,7 @@
  *   - return value 0 = success, negative = error (ur_last_error() gives the message, thread-local);
  *   - floating point is fp32, face indices are int32 (pytorch3d uses int64; the Python layer widens on demand);
  *   - pix_to_face holds PACKED face indices (mesh n's faces start at mesh_first_face[n]), -1 = empty slot;
- *   - the library is stateless and thread-safe.
+ *   - the library is stateless and thread-safe (the opt-in ur_profile_* timing hook aside).
  */
 #ifndef UNICORN_RENDER_H
 #define UNICORN_RENDER_H
@@ -54,8 +54,9 @@ int ur_abi_version(void);
 int ur_profile_begin(int max_launches);
 int ur_profile_end(float* ms, int* kinds, int capacity, int* count);
 
-/* Bytes of device workspace the raster / render entry points need: per-face records for `total_faces` packed faces
- * plus, when faces_per_pixel K exceeds what the LDS holds per pixel, a spill area for the per-pixel top-K lists. */
+/* Bytes of device workspace the raster / render entry points need: per-face records for `total_faces` packed faces,
+ * the workgroup schedule (two ints per 16x16 bin) plus, when faces_per_pixel K exceeds what the LDS holds per pixel, a
+ * spill area for the per-pixel top-K lists. */
 size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K);
 
 /*
@@ -82,8 +83,8 @@ int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t 
  * Replaces: pytorch3d._C.rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh,
  *           clipped_faces_neighbor_idx, image_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin,
  *           perspective_correct, clip_barycentric_coords, cull_backfaces), call site renderer.py:46-49,54-57.
- * There is no bin_size / max_faces_per_bin: binning is internal (16x16 bins -> 8x8 tiles, lists in LDS, processed
- * in rounds) and cannot overflow; any faces_per_pixel is accepted.  perspective_correct must be 0 (the reference never enables it, renderer.py:47,55).
+ * There is no bin_size / max_faces_per_bin: binning is internal (16x16 bins, lists in LDS, processed in rounds of
+ * 2048 faces, bins scheduled heaviest first) and cannot overflow; any faces_per_pixel is accepted.  perspective_correct must be 0 (the reference never enables it, renderer.py:47,55).
  *   face_verts (NF,3,3) ; mesh_first_face, mesh_num_faces (N) int64 ;
  *   outputs (N,H,W,K): pix_to_face int32, zbuf, dists fp32 ; bary (N,H,W,K,3).  Any of zbuf/bary/dists may be NULL.
  */
@@ -138,10 +139,11 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
  *           the autograd of both (trainer.py:151).  Numerically identical to ur_rasterize_meshes + ur_shade_blend:
  * the blend stops at the first layer that hides everything behind it (alpha == 1 with zero d(alpha)/d(dist)), which
  * changes neither the image nor any gradient.  No (N,H,W,K) fragment tensors are materialised: the forward leaves
- * only `layers`, ur_layers_elems() int32 words laid out [N][ceil(H/8)][ceil(W/8)][K][6][64]: per 8x8 tile, per depth
- * slot, six 64-pixel planes (packed face index; float bits of the transmittance in front of the layer, its alpha and
- * its colour) of the layers that matter, front to back, ended by face = -1.  Only the first few depth slots of a tile
- * are ever touched.  The backward also needs ur_backward_scratch_bytes() of uninitialised device scratch.
+ * only `layers`, ur_layers_elems() int32 words, opaque to the caller: per 16x16-pixel bin and per wavefront of the
+ * bin (4 x 64 pixels, every second column / row), per depth slot, six 64-pixel planes (packed face index; float bits
+ * of the transmittance in front of the layer, its alpha and its colour) of the layers that matter, front to back,
+ * followed by the per-pixel layer counts.  Only the first few depth slots are ever touched.  The backward also needs
+ * ur_backward_scratch_bytes() of uninitialised device scratch.
  *   workspace: ur_workspace_bytes(total_faces, N, H, W, K) bytes; the backward must be given the SAME buffer, untouched.
  *   grad_face_verts (NF,3,3) and grad_maps (N,Ht,Wt,3) must be zero-filled by the caller; either may be NULL
  *   (then that gradient is skipped).  The z column of grad_face_verts stays 0 (the layered blend never reads zbuf).

@@ -1,17 +1,18 @@
 // ur_render.hip -- hand-written gfx950 (MI355X) kernels + the C ABI of include/unicorn_render.h.
 //
-// Execution model of the rasterizer (ur_rasterize_meshes / ur_tile_faces):
-//   * one WAVEFRONT owns one 8x8 pixel tile, lane = pixel (row-major inside the tile);
-//   * a workgroup of WPB waves (4, 2 or 1, chosen from K so that the per-lane top-K lists fit the 160 KB LDS) owns a
-//     coarse bin of 16x16 / 16x8 / 8x8 pixels;
-//   * coarse step: the workgroup scans the mesh's face bounding boxes (one face per thread, coalesced float4), a
-//     wave ballot + popcount prefix appends survivors to the bin list in LDS in ascending face order -- no atomics, so
-//     the lists are deterministic; the list is consumed in rounds, it cannot overflow;
-//   * fine step: each wave filters 64 bin entries at a time against its own tile (ballot again) and walks the set
-//     bits; the face record is read through a wave-uniform address, every lane tests its own pixel;
-//   * per-lane top-K: K (depth, face) keys packed as u64 = (bits(z) << 32 | face) in LDS, laid out [slot][lane] so
-//     that lane-consecutive 8-byte accesses are bank-conflict free; z >= 0, so unsigned order == (z, face) order;
-//   * output: keys are extracted in ascending order, barycentrics / distance are recomputed for the winners only.
+// Execution model (DESIGN.md 5 has the long version):
+//   * k_face_prep: one thread per face -> bounding box, per-face record (corners, denominators, RN reciprocals), and
+//     a per-bin load count; k_bin_order sorts the 16x16-pixel bins of all meshes heaviest first;
+//   * k_raster<MODE>: one workgroup (4 waves) per bin, taken from that schedule.  Coarse step: the workgroup scans the
+//     mesh's face boxes (up to 8 coalesced float4 per lane), ballot + popcount prefix packs survivors into one bin
+//     list in LDS -- no atomics, deterministic; rounds of 2048 faces, the list cannot overflow.  Fine step: 64 bin
+//     faces at a time staged in LDS (double buffered).  MODE 0 (fragments): lane = pixel, faces walked one by one.
+//     MODE 2 (fused shading): (face, pixel) pairs dealt over the lanes, hits appended to per-pixel lists with LDS
+//     integer atomics.  MODE 1: tile lists exported;
+//   * per-pixel top-K: (depth, face) keys packed as u64 in LDS, [slot][pixel]; z >= 0, so unsigned order == (z, face)
+//     order; lists past the LDS cap continue in a global spill area;
+//   * MODE 2 tail: sort, (pixel, layer) items dealt over the lanes, UV sample + layered blend, layer records saved
+//     for k_render_bwd, which deals the same items again and scatters gradients through f64 LDS tables.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
