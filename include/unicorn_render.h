@@ -36,6 +36,7 @@ extern "C" {
 #define UR_BLEND_HARD 0        /* sigma == 0        : alpha = (dist <= 0)                      */
 #define UR_BLEND_CLIP_INSIDE 1 /* clip_inside=True  : alpha = exp(-max(dist, 0) / sigma)       */
 #define UR_BLEND_SIGMOID 2     /* clip_inside=False : alpha = sigmoid(-dist / sigma)           */
+#define UR_BLEND_SOFTMAX 3     /* ur_blend_colors only: pytorch3d softmax_rgb_blend            */
 
 const char* ur_last_error(void);
 int ur_abi_version(void);
@@ -132,6 +133,26 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
                             const int64_t* mesh_first_face, int N, int H, int W, int K, int Ht, int Wt, float sigma,
                             const float* background, const float* ambient, int mode, float* grad_maps,
                             float* grad_bary, float* grad_dists, void* stream);
+
+/*
+ * Blending of per-fragment colours computed by the caller (lit colours of phong / flat / gouraud shading).
+ * Replaces: layered_rgb_blend(colors, fragments, blend_params, clip_inside) (renderer.py:172,175-202) for
+ *           kind = UR_BLEND_HARD / CLIP_INSIDE / SIGMOID, and pytorch3d's softmax_rgb_blend(colors, fragments,
+ *           blend_params, znear, zfar), reached through SoftPhongShaderPlus (renderer.py:205-208, the
+ *           layered_shader=False branch of renderer.py:38-43), for kind = UR_BLEND_SOFTMAX:
+ *   prob = sigmoid(-dists/sigma)*mask ; A = 1 - prod(1-prob) ; z_inv = (zfar-zbuf)/(zfar-znear)*mask ;
+ *   w = prob*exp((z_inv - max(z_inv_max,1e-10))/gamma) ; delta = max(exp((1e-10 - z_inv_max)/gamma), 1e-10) ;
+ *   rgb = (sum w c + delta bg) / (sum w + delta).
+ *   colors (N,H,W,K,3) ; pix_to_face / dists / zbuf (N,H,W,K) (zbuf may be NULL unless softmax) -> image (N,4,H,W).
+ * Backward: grad_image -> grad_colors, grad_dists (fully written) and grad_zbuf (may be NULL; zero unless softmax).
+ */
+int ur_blend_colors(const float* colors, const int32_t* pix_to_face, const float* dists, const float* zbuf, int N,
+                    int H, int W, int K, int kind, float sigma, float gamma, const float* background, float znear,
+                    float zfar, float* image, void* stream);
+int ur_blend_colors_backward(const float* grad_image, const float* colors, const int32_t* pix_to_face,
+                             const float* dists, const float* zbuf, int N, int H, int W, int K, int kind, float sigma,
+                             float gamma, const float* background, float znear, float zfar, float* grad_colors,
+                             float* grad_dists, float* grad_zbuf, void* stream);
 
 /*
  * Fused training path: rasterize + UV-sample + layered blend in ONE launch, and its backward in ONE launch.

@@ -179,6 +179,19 @@ def softmax_blend(colors, pix_to_face, dists, zbuf, sigma, gamma, background, zn
     return img
 
 
+def softmax_blend_bwd(colors, pix_to_face, dists, zbuf, grad_image, sigma, gamma, background, znear=1.0, zfar=100.0,
+                      dtype=np.float32):
+    col, p2f, ds, zb = _c(colors, dtype), _c(pix_to_face, np.int64), _c(dists, dtype), _c(zbuf, dtype)
+    bg, gimg = _c(background, dtype), _c(grad_image, dtype)
+    N, H, W, K = p2f.shape
+    gcol, gds, gzb = np.empty_like(col), np.empty_like(ds), np.empty_like(zb)
+    getattr(lib(), "orc_softmax_blend_bwd_" + _sfx(dtype))(_p(col), _p(p2f), _p(ds), _p(zb), _p(gimg), N, H, W, K,
+                                                          _real(dtype, sigma), _real(dtype, gamma), _p(bg),
+                                                          _real(dtype, znear), _real(dtype, zfar), _p(gcol), _p(gds),
+                                                          _p(gzb))
+    return gcol, gds, gzb
+
+
 def render_fwd_bwd(verts, faces, R, T, maps, verts_uvs, H, W, K, s, sigma=1e-4, background=(1., 1., 1.),
                    clip_inside=True, grad_image=None, n_threads=1, blur_radius=None, dtype=np.float32):
     """Whole path on the CPU.  verts (N,V,3), faces (F,3) shared topology, maps (N,Ht,Wt,3), verts_uvs (N,V,2).

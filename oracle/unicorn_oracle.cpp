@@ -592,6 +592,74 @@ void softmax_blend_fwd(const T* colors, const int64_t* pix_to_face, const T* dis
     }
 }
 
+// Backward of softmax_blend_fwd, following torch autograd's rules for the published formula: max() sends its
+// gradient to the first maximal entry, clamp(min=) passes where the input is >= the bound, prod() is differentiated
+// exactly (also with zero factors).  grad_image (N,4,H,W) -> grad_colors (N,H,W,K,3), grad_dists, grad_zbuf (N,H,W,K).
+template <typename T>
+void softmax_blend_bwd(const T* colors, const int64_t* pix_to_face, const T* dists, const T* zbuf, const T* grad_image,
+                       int N, int H, int W, int K, T sigma, T gamma, const T* bg, T znear, T zfar, T* g_colors,
+                       T* g_dists, T* g_zbuf) {
+  const T eps = T(1e-10);
+  std::vector<T> prob(K), zinv(K), w(K);
+  for (int n = 0; n < N; ++n)
+    for (int64_t p = 0; p < (int64_t)H * W; ++p) {
+      const int64_t base = ((int64_t)n * H * W + p) * K;
+      T g[4];
+      for (int c = 0; c < 4; ++c) g[c] = grad_image[((int64_t)n * 4 + c) * H * W + p];
+      T zraw = T(0);
+      int kmax = 0;
+      for (int k = 0; k < K; ++k) {
+        const bool valid = pix_to_face[base + k] >= 0;
+        prob[k] = valid ? T(1) / (T(1) + std::exp(dists[base + k] / sigma)) : T(0);
+        zinv[k] = valid ? (zfar - zbuf[base + k]) / (zfar - znear) : T(0);
+        if (k == 0 || zinv[k] > zraw) { zraw = zinv[k]; kmax = k; }
+      }
+      const T zmax = std::max(zraw, eps);
+      const T delta_raw = std::exp((eps - zmax) / gamma);
+      const T delta = std::max(delta_raw, eps);
+      T denom = delta, S[3] = {delta * bg[0], delta * bg[1], delta * bg[2]};
+      for (int k = 0; k < K; ++k) {
+        w[k] = prob[k] * std::exp((zinv[k] - zmax) / gamma);
+        denom += w[k];
+        for (int c = 0; c < 3; ++c) S[c] += w[k] * colors[(base + k) * 3 + c];
+      }
+      T rgb_dot = T(0);  // g_rgb . rgb
+      for (int c = 0; c < 3; ++c) rgb_dot += g[c] * (S[c] / denom);
+      // product of (1 - prob_j) over j != k, exact with zero factors
+      int zeros = 0, kzero = -1;
+      T prod_nz = T(1);
+      for (int k = 0; k < K; ++k) {
+        const T f = T(1) - prob[k];
+        if (f == T(0)) { ++zeros; kzero = k; } else prod_nz *= f;
+      }
+      T g_zmax = T(0);
+      for (int k = 0; k < K; ++k) {
+        const bool valid = pix_to_face[base + k] >= 0;
+        T gc_dot = T(0);
+        for (int c = 0; c < 3; ++c) {
+          g_colors[(base + k) * 3 + c] = g[c] * w[k] / denom;
+          gc_dot += g[c] * colors[(base + k) * 3 + c];
+        }
+        const T g_w = (gc_dot - rgb_dot) / denom;
+        const T e = std::exp((zinv[k] - zmax) / gamma);
+        T g_prob = g_w * e;
+        const T g_zinv = g_w * w[k] / gamma;
+        g_zmax -= g_w * w[k] / gamma;
+        // alpha channel: A = 1 - prod (1 - prob)  =>  dA/dprob_k = prod_{j != k} (1 - prob_j)
+        const T others = zeros == 0 ? prod_nz / (T(1) - prob[k]) : (zeros == 1 && k == kzero ? prod_nz : T(0));
+        g_prob += g[3] * others;
+        g_dists[base + k] = valid ? g_prob * prob[k] * (T(1) - prob[k]) * (-T(1) / sigma) : T(0);
+        g_zbuf[base + k] = valid ? -g_zinv / (zfar - znear) : T(0);
+      }
+      // the background weight
+      T gbg_dot = T(0);
+      for (int c = 0; c < 3; ++c) gbg_dot += g[c] * bg[c];
+      const T g_delta = (gbg_dot - rgb_dot) / denom;
+      if (delta_raw >= eps) g_zmax -= g_delta * delta_raw / gamma;
+      if (zraw >= eps && pix_to_face[base + kmax] >= 0) g_zbuf[base + kmax] += -g_zmax / (zfar - znear);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // render_fwd_bwd: the whole path for one batch (CPU baseline of bench.py and end-to-end parity):
 // project -> gather faces -> rasterize -> sample -> layered blend, then the backward of all of it
@@ -711,6 +779,11 @@ template <typename T> void render_fwd_bwd(const RenderArgs<T>& a, int n_threads)
                                               int H, int W, int K, T sigma, T gamma, const T* bg, T znear, T zfar,    \
                                               T* image) {                                                             \
     softmax_blend_fwd<T>(col, p2f, ds, zb, N, H, W, K, sigma, gamma, bg, znear, zfar, image);                         \
+  }                                                                                                                   \
+  extern "C" void orc_softmax_blend_bwd_##SFX(const T* col, const int64_t* p2f, const T* ds, const T* zb,             \
+                                              const T* gimg, int N, int H, int W, int K, T sigma, T gamma,            \
+                                              const T* bg, T znear, T zfar, T* gcol, T* gds, T* gzb) {                \
+    softmax_blend_bwd<T>(col, p2f, ds, zb, gimg, N, H, W, K, sigma, gamma, bg, znear, zfar, gcol, gds, gzb);          \
   }                                                                                                                   \
   extern "C" void orc_render_fwd_bwd_##SFX(const T* verts, const int64_t* faces, const T* R, const T* Tr,             \
                                            const T* maps, const T* verts_uvs, int N, int V, int F, int H, int W,      \

@@ -180,7 +180,7 @@ def test_init_kwargs_roundtrip_and_unsupported():
     assert r.init_kwargs == kw and r.init_kwargs is not r.init_kwargs
     assert Renderer(64, **r.init_kwargs).renderer.rasterizer.raster_settings.faces_per_pixel == 50
     with pytest.raises(NotImplementedError):
-        Renderer(64, layered_shader=False)
+        Renderer(64, shading_type="toon")
 
 
 def test_fused_equals_two_stage_bitwise_forward():

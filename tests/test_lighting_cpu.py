@@ -1,0 +1,88 @@
+"""Lighting (unicorn_amd/lighting.py: the reference's diffuse / specular / _apply_lighting, pytorch3d_monkey.py:34-198,
+and pytorch3d's phong / flat shading) against an independent numpy restatement.  Pure torch ops: runs on the CPU.
+Parity unpinned: pytorch3d is not available, the numpy code below restates the same published formulas."""
+import numpy as np
+import torch
+
+from unicorn_amd import lighting, synth
+from unicorn_amd.renderer import DirectionalLights, PointLights, AmbientLights, Fragments
+from unicorn_amd.structures import Meshes, TexturesUV
+
+
+def _norm(v, eps=1e-6):
+    return v / np.maximum(np.linalg.norm(v, axis=-1, keepdims=True), eps)
+
+
+def _np_light(points, normals, cam, lights, shininess=64.0):
+    amb = np.asarray(lights.ambient_color, np.float64).reshape(1, 3)
+    if not hasattr(lights, "diffuse_color"):
+        return amb, np.zeros_like(points), np.zeros_like(points)
+    d = (np.asarray(lights.location, np.float64).reshape(1, 3) - points) if hasattr(lights, "location") \
+        else np.broadcast_to(np.asarray(lights.direction, np.float64).reshape(1, 3), points.shape)
+    n, d = _norm(normals), _norm(d)
+    cos = (n * d).sum(-1)
+    dif = np.asarray(lights.diffuse_color, np.float64).reshape(1, 3) * np.maximum(cos, 0)[..., None]
+    view = _norm(cam - points)
+    refl = -d + 2 * cos[..., None] * n
+    al = np.maximum((view * refl).sum(-1), 0) * (cos > 0)
+    spe = np.asarray(lights.specular_color, np.float64).reshape(1, 3) * (al ** shininess)[..., None]
+    return amb, dif, spe
+
+
+def _scene(N=2, H=6, W=5, K=3, seed=0):
+    sc = synth.make_scene(N, level=1, tex_size=8, seed=seed)
+    F = sc["faces"].shape[0]
+    rs = np.random.RandomState(seed)
+    p2f = rs.randint(-1, F, (N, H, W, K)).astype(np.int64)
+    p2f[p2f >= 0] += (np.arange(N).reshape(N, 1, 1, 1) * F).repeat(H, 1).repeat(W, 2).repeat(K, 3)[p2f >= 0]
+    bary = rs.dirichlet((1, 1, 1), (N, H, W, K)).astype(np.float32)
+    fb, ub = sc["faces"][None].expand(N, -1, -1), sc["verts_uvs"][None].expand(N, -1, -1)
+    meshes = Meshes(verts=sc["verts"].double(), faces=fb, textures=TexturesUV(sc["maps"].double(), fb, ub))
+    frag = Fragments(torch.tensor(p2f, dtype=torch.int32), None, torch.tensor(bary).double(), None)
+    return sc, meshes, frag, p2f, bary.astype(np.float64)
+
+
+def test_vertex_and_face_normals():
+    sc, meshes, *_ = _scene()
+    v, f = meshes.verts_packed().numpy(), meshes.faces_packed().numpy()
+    fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    vn = np.zeros_like(v)
+    for i in range(3):
+        np.add.at(vn, f[:, i], fn)  # the cross product of the two edges at any corner is the same vector
+    np.testing.assert_allclose(meshes.faces_normals_packed().numpy(), _norm(fn), atol=1e-12)
+    np.testing.assert_allclose(meshes.verts_normals_packed().numpy(), _norm(vn), atol=1e-12)
+    # an icosphere's vertex normals point outwards
+    assert (np.sum(_norm(vn)[:v.shape[0] // 2] * _norm(v[:v.shape[0] // 2] - v[:v.shape[0] // 2].mean(0)), -1) > 0.5).all()
+
+
+def test_phong_and_flat_shading_match_numpy():
+    sc, meshes, frag, p2f, bary = _scene()
+    N = p2f.shape[0]
+    R, T = sc["R"].double(), sc["T"].double()
+    cam = (-(T[:, None] @ R.transpose(1, 2))[:, 0]).numpy().reshape(N, 1, 1, 1, 3)
+    texels = torch.rand(p2f.shape + (3,), dtype=torch.float64)
+    v, f = meshes.verts_packed().numpy(), meshes.faces_packed().numpy()
+    vn = meshes.verts_normals_packed().numpy()
+    mask = (p2f >= 0)[..., None]
+    idx = np.maximum(p2f, 0)
+    pts = (bary[..., None] * v[f][idx]).sum(-2) * mask
+    nrm = (bary[..., None] * vn[f][idx]).sum(-2) * mask
+    for lights in (DirectionalLights(direction=((0.3, -0.2, -1.0),)), PointLights(location=((0.5, 1.0, -2.0),)),
+                   AmbientLights(ambient_color=((0.7, 0.8, 0.9),))):
+        amb, dif, spe = _np_light(pts, nrm, cam, lights)
+        want = (amb + dif) * texels.numpy() + spe
+        got = lighting.phong_shading(meshes, frag, lights, lighting.Materials(), texels, R, T).numpy()
+        np.testing.assert_allclose(got, want, atol=1e-6)
+    lights = DirectionalLights(direction=((0.0, 0.0, -1.0),))
+    cen = v[f].mean(1)[idx] * mask
+    fnr = meshes.faces_normals_packed().numpy()[idx] * mask
+    amb, dif, spe = _np_light(cen, fnr, cam, lights)
+    got = lighting.flat_shading(meshes, frag, lights, lighting.Materials(), texels, R, T).numpy()
+    np.testing.assert_allclose(got, (amb + dif) * texels.numpy() + spe, atol=1e-6)
+
+
+def test_camera_center_inverts_the_view_transform():
+    sc, *_ = _scene()
+    R, T = sc["R"], sc["T"]
+    c = lighting.camera_center(R, T)
+    np.testing.assert_allclose((torch.bmm(c[:, None], R)[:, 0] + T).numpy(), 0.0, atol=1e-5)

@@ -1688,6 +1688,197 @@ __global__ void __launch_bounds__(256) k_selftest_division(unsigned long long n,
   if (bad) atomicAdd(mismatches, bad);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// blending of per-fragment colours that the caller computed (lit colours of phong / flat / gouraud shading):
+// kind 0..2 = layered_rgb_blend's three alpha modes (renderer.py:175-202), kind 3 = pytorch3d's softmax_rgb_blend
+// (reached through SoftPhongShaderPlus, renderer.py:205-208).  One thread per pixel, K fragments each.
+// ------------------------------------------------------------------------------------------------------------------
+struct BlendParamsK {
+  const float* colors;   // (N,H,W,K,3)
+  const int32_t* p2f;    // (N,H,W,K)
+  const float* dists;
+  const float* zbuf;     // softmax only
+  int N, H, W, K, kind;
+  float sigma, gamma, znear, zfar;
+  float bg[3];
+  float* image;          // (N,4,H,W)
+  const float* gimage;
+  float* gcolors;
+  float* gdists;
+  float* gzbuf;
+};
+
+constexpr float kSoftEps = 1e-10f;
+
+// sigma == 0 (the viz settings, renderer.py:53): sigmoid(-d/0) is a step; d == 0 would be 0/0, taken as covered
+__device__ __forceinline__ float soft_prob(float d, bool valid, float sigma) {
+  if (!valid) return 0.0f;
+  if (sigma == 0.0f) return d <= 0.0f ? 1.0f : 0.0f;
+  return 1.0f / (1.0f + expf(d / sigma));
+}
+
+__global__ void __launch_bounds__(256) k_blend_fwd(const BlendParamsK P) {
+  const int64_t npix = (int64_t)P.N * P.H * P.W;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int64_t hw = (int64_t)P.H * P.W;
+  const int n = (int)(pix / hw);
+  const int64_t p = pix - (int64_t)n * hw;
+  float* img = P.image + (int64_t)n * 4 * hw + p;
+  const int64_t base = pix * P.K;
+  if (P.kind < 3) {
+    float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+    for (int k = 0; k < P.K; ++k) {
+      const int64_t e = base + k;
+      const float a = layer_alpha(P.dists[e], P.p2f[e] >= 0, P.sigma, P.kind);
+      r += occ * a * P.colors[e * 3 + 0]; g += occ * a * P.colors[e * 3 + 1]; b += occ * a * P.colors[e * 3 + 2];
+      occ = occ * (1.0f - a);
+    }
+    img[0] = r + occ * 1.0f * P.bg[0];
+    img[hw] = g + occ * 1.0f * P.bg[1];
+    img[2 * hw] = b + occ * 1.0f * P.bg[2];
+    img[3 * hw] = 1.0f - occ;
+    return;
+  }
+  const float zden = P.zfar - P.znear;
+  float alpha = 1.0f, zmax = 0.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    alpha *= (1.0f - soft_prob(P.dists[e], valid, P.sigma));
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    zmax = (k == 0) ? zinv : max_s(zmax, zinv);
+  }
+  zmax = max_s(zmax, kSoftEps);
+  const float delta = max_s(expf((kSoftEps - zmax) / P.gamma), kSoftEps);
+  float denom = delta, r = 0.0f, g = 0.0f, b = 0.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    const float w = soft_prob(P.dists[e], valid, P.sigma) * expf((zinv - zmax) / P.gamma);
+    denom += w;
+    r += w * P.colors[e * 3 + 0]; g += w * P.colors[e * 3 + 1]; b += w * P.colors[e * 3 + 2];
+  }
+  img[0] = (r + delta * P.bg[0]) / denom;
+  img[hw] = (g + delta * P.bg[1]) / denom;
+  img[2 * hw] = (b + delta * P.bg[2]) / denom;
+  img[3 * hw] = 1.0f - alpha;
+}
+
+__global__ void __launch_bounds__(256) k_blend_bwd(const BlendParamsK P) {
+  const int64_t npix = (int64_t)P.N * P.H * P.W;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int64_t hw = (int64_t)P.H * P.W;
+  const int n = (int)(pix / hw);
+  const int64_t p = pix - (int64_t)n * hw;
+  const float* gi = P.gimage + (int64_t)n * 4 * hw + p;
+  const float g0 = gi[0], g1 = gi[hw], g2 = gi[2 * hw], g3 = gi[3 * hw];
+  const int64_t base = pix * P.K;
+  if (P.kind < 3) {
+    // transmittance in front of every layer is recomputed front to back on the way (two sweeps, no scratch):
+    // first the total, then back to front dividing out is inexact -- so sweep forward per layer instead: O(K^2)
+    // would be wasteful; keep the forward products in the gradient buffers (gdists as scratch) and read them back
+    float occ = 1.0f;
+    for (int k = 0; k < P.K; ++k) {
+      const int64_t e = base + k;
+      P.gdists[e] = occ;
+      occ = occ * (1.0f - layer_alpha(P.dists[e], P.p2f[e] >= 0, P.sigma, P.kind));
+    }
+    float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+    float trans = 1.0f;
+    for (int k = P.K - 1; k >= 0; --k) {
+      const int64_t e = base + k;
+      const bool valid = P.p2f[e] >= 0;
+      const float d = P.dists[e];
+      const float a = layer_alpha(d, valid, P.sigma, P.kind);
+      const float ok = P.gdists[e];
+      const float c0 = P.colors[e * 3 + 0], c1 = P.colors[e * 3 + 1], c2 = P.colors[e * 3 + 2];
+      const float cg = g0 * c0 + g1 * c1 + g2 * c2;
+      const float ga = ok * (cg - behind) + g3 * ok * trans;
+      P.gdists[e] = ga * layer_dalpha(d, a, valid, P.sigma, P.kind);
+      const float wgt = ok * a;
+      P.gcolors[e * 3 + 0] = wgt * g0; P.gcolors[e * 3 + 1] = wgt * g1; P.gcolors[e * 3 + 2] = wgt * g2;
+      if (P.gzbuf) P.gzbuf[e] = 0.0f;
+      behind = a * cg + (1.0f - a) * behind;
+      trans = trans * (1.0f - a);
+    }
+    return;
+  }
+  // ---- softmax blend: torch autograd's rules for the published formula (max -> first maximal entry, clamp(min)
+  //      passes where the input is >= the bound, prod differentiated exactly also with zero factors)
+  const float zden = P.zfar - P.znear;
+  float zraw = 0.0f;
+  int kmax = 0, zeros = 0, kzero = -1;
+  float prod_nz = 1.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    const float pr = soft_prob(P.dists[e], valid, P.sigma);
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    if (k == 0 || zinv > zraw) { zraw = zinv; kmax = k; }
+    const float f = 1.0f - pr;
+    if (f == 0.0f) { ++zeros; kzero = k; } else prod_nz *= f;
+  }
+  const float zmax = max_s(zraw, kSoftEps);
+  const float delta_raw = expf((kSoftEps - zmax) / P.gamma);
+  const float delta = max_s(delta_raw, kSoftEps);
+  float denom = delta, S0 = delta * P.bg[0], S1 = delta * P.bg[1], S2 = delta * P.bg[2];
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    const float w = soft_prob(P.dists[e], valid, P.sigma) * expf((zinv - zmax) / P.gamma);
+    denom += w;
+    S0 += w * P.colors[e * 3 + 0]; S1 += w * P.colors[e * 3 + 1]; S2 += w * P.colors[e * 3 + 2];
+  }
+  const float rgb_dot = g0 * (S0 / denom) + g1 * (S1 / denom) + g2 * (S2 / denom);
+  float g_zmax = 0.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    const float pr = soft_prob(P.dists[e], valid, P.sigma);
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    const float ex = expf((zinv - zmax) / P.gamma);
+    const float w = pr * ex;
+    const float c0 = P.colors[e * 3 + 0], c1 = P.colors[e * 3 + 1], c2 = P.colors[e * 3 + 2];
+    P.gcolors[e * 3 + 0] = g0 * w / denom; P.gcolors[e * 3 + 1] = g1 * w / denom; P.gcolors[e * 3 + 2] = g2 * w / denom;
+    const float g_w = ((g0 * c0 + g1 * c1 + g2 * c2) - rgb_dot) / denom;
+    float g_prob = g_w * ex;
+    const float g_zinv = g_w * w / P.gamma;
+    g_zmax -= g_w * w / P.gamma;
+    const float others = zeros == 0 ? prod_nz / (1.0f - pr) : ((zeros == 1 && k == kzero) ? prod_nz : 0.0f);
+    g_prob += g3 * others;
+    P.gdists[e] = (valid && P.sigma > 0.0f) ? g_prob * pr * (1.0f - pr) * (-1.0f / P.sigma) : 0.0f;
+    if (P.gzbuf) P.gzbuf[e] = valid ? -g_zinv / zden : 0.0f;
+  }
+  const float g_delta = ((g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2]) - rgb_dot) / denom;
+  if (delta_raw >= kSoftEps) g_zmax -= g_delta * delta_raw / P.gamma;
+  if (P.gzbuf && zraw >= kSoftEps && P.p2f[base + kmax] >= 0) P.gzbuf[base + kmax] += -g_zmax / zden;
+}
+
+int fill_blend_params(BlendParamsK& P, const float* colors, const int32_t* p2f, const float* dists, const float* zbuf,
+                      int N, int H, int W, int K, int kind, float sigma, float gamma, const float* bg, float znear,
+                      float zfar) {
+  if (!colors || !p2f || !dists || !bg) return fail(UR_ERR_INVALID_ARG, "null input pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (kind < 0 || kind > 3) return fail(UR_ERR_INVALID_ARG, "bad blend kind %d", kind);
+  if ((kind == UR_BLEND_CLIP_INSIDE || kind == UR_BLEND_SIGMOID) && !(sigma > 0.0f))
+    return fail(UR_ERR_INVALID_ARG, "sigma must be > 0 for soft blending");
+  if (kind == UR_BLEND_SOFTMAX) {
+    if (!(sigma >= 0.0f)) return fail(UR_ERR_INVALID_ARG, "sigma must be >= 0");
+    if (!zbuf) return fail(UR_ERR_INVALID_ARG, "softmax blend needs zbuf");
+    if (!(gamma > 0.0f) || !(zfar > znear)) return fail(UR_ERR_INVALID_ARG, "softmax blend needs gamma > 0, zfar > znear");
+  }
+  P.colors = colors; P.p2f = p2f; P.dists = dists; P.zbuf = zbuf;
+  P.N = N; P.H = H; P.W = W; P.K = K; P.kind = kind;
+  P.sigma = sigma; P.gamma = gamma; P.znear = znear; P.zfar = zfar;
+  for (int i = 0; i < 3; ++i) P.bg[i] = bg[i];
+  P.image = nullptr; P.gimage = nullptr; P.gcolors = nullptr; P.gdists = nullptr; P.gzbuf = nullptr;
+  return UR_OK;
+}
+
 int fill_shade_params(ShadeParams& P, const int32_t* p2f, const float* bary, const float* dists, const float* maps,
                       const float* fuv, int fuv_shared, const int64_t* first, int N, int H, int W, int K, int Ht, int Wt,
                       float sigma, const float* bg, const float* amb, int mode) {
@@ -1884,6 +2075,37 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
   if (lds > 64 * 1024) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d too large for the blend backward", K);
   hipLaunchKernelGGL(k_shade_bwd, dim3((unsigned)((npix + 63) / 64)), dim3(64), lds, (hipStream_t)stream, P);
   return check_launch("k_shade_bwd");
+}
+
+int ur_blend_colors(const float* colors, const int32_t* pix_to_face, const float* dists, const float* zbuf, int N,
+                    int H, int W, int K, int kind, float sigma, float gamma, const float* background, float znear,
+                    float zfar, float* image, void* stream) {
+  BlendParamsK P{};
+  int rc = fill_blend_params(P, colors, pix_to_face, dists, zbuf, N, H, W, K, kind, sigma, gamma, background, znear,
+                             zfar);
+  if (rc) return rc;
+  if (!image) return fail(UR_ERR_INVALID_ARG, "null output pointer");
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  P.image = image;
+  hipLaunchKernelGGL(k_blend_fwd, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+  return check_launch("k_blend_fwd");
+}
+
+int ur_blend_colors_backward(const float* grad_image, const float* colors, const int32_t* pix_to_face,
+                             const float* dists, const float* zbuf, int N, int H, int W, int K, int kind, float sigma,
+                             float gamma, const float* background, float znear, float zfar, float* grad_colors,
+                             float* grad_dists, float* grad_zbuf, void* stream) {
+  BlendParamsK P{};
+  int rc = fill_blend_params(P, colors, pix_to_face, dists, zbuf, N, H, W, K, kind, sigma, gamma, background, znear,
+                             zfar);
+  if (rc) return rc;
+  if (!grad_image || !grad_colors || !grad_dists) return fail(UR_ERR_INVALID_ARG, "null gradient pointer");
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  P.gimage = grad_image; P.gcolors = grad_colors; P.gdists = grad_dists; P.gzbuf = grad_zbuf;
+  hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+  return check_launch("k_blend_bwd");
 }
 
 int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* stream) {

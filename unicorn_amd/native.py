@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNICORN_RENDER_LIB: load another build of the same library (A/B timing of two builds on one box)
 LIB_PATH = os.environ.get("UNICORN_RENDER_LIB") or os.path.join(_HERE, "lib", "libunicorn_render.so")
 
-BLEND_HARD, BLEND_CLIP_INSIDE, BLEND_SIGMOID = 0, 1, 2
+BLEND_HARD, BLEND_CLIP_INSIDE, BLEND_SIGMOID, BLEND_SOFTMAX = 0, 1, 2, 3
 
 _lib = None
 
@@ -32,6 +32,9 @@ _SIGNATURES = {
     "ur_rasterize_meshes_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "ur_tile_faces": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ur_shade_blend": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
+    "ur_blend_colors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _f, _f, _vp, _vp]),
+    "ur_blend_colors_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _f, _f, _vp, _vp, _vp,
+                                      _vp]),
     "ur_layers_elems": (_sz, [_i, _i, _i, _i]),
     "ur_selftest_division": (_i, [ctypes.c_uint64, ctypes.c_uint32, _vp, _vp]),
     "ur_render_layered_forward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
@@ -266,6 +269,33 @@ def shade_blend_backward(grad_image, pix_to_face, bary, dists, maps, face_uvs, f
                                              int(mode), _ptr(gmaps, None, True), _ptr(gbary), _ptr(gdists),
                                              _stream(maps)), "ur_shade_blend_backward")
     return gmaps, gbary, gdists
+
+
+def blend_colors(colors, pix_to_face, dists, zbuf, kind, sigma, gamma, background, znear=1.0, zfar=100.0):
+    """per-fragment colours (N,H,W,K,3) -> image (N,4,H,W); kind BLEND_HARD / CLIP_INSIDE / SIGMOID / SOFTMAX"""
+    N, H, W, K = pix_to_face.shape
+    image = torch.empty(N, 4, H, W, dtype=torch.float32, device=colors.device)
+    with _on(colors), _timed("ur_blend_colors", colors):
+        _check(lib().ur_blend_colors(_ptr(colors, torch.float32), _ptr(pix_to_face, torch.int32),
+                                     _ptr(dists, torch.float32), _ptr(zbuf, torch.float32, True), N, H, W, K,
+                                     int(kind), float(sigma), float(gamma), ctypes.cast(_rgb(background), _vp),
+                                     float(znear), float(zfar), _ptr(image), _stream(colors)), "ur_blend_colors")
+    return image
+
+
+def blend_colors_backward(grad_image, colors, pix_to_face, dists, zbuf, kind, sigma, gamma, background, znear=1.0,
+                          zfar=100.0):
+    N, H, W, K = pix_to_face.shape
+    gcol, gd = torch.empty_like(colors), torch.empty_like(dists)
+    gz = torch.empty_like(dists) if zbuf is not None else None
+    with _on(colors), _timed("ur_blend_colors_backward", colors):
+        _check(lib().ur_blend_colors_backward(_ptr(grad_image, torch.float32), _ptr(colors, torch.float32),
+                                              _ptr(pix_to_face, torch.int32), _ptr(dists, torch.float32),
+                                              _ptr(zbuf, torch.float32, True), N, H, W, K, int(kind), float(sigma),
+                                              float(gamma), ctypes.cast(_rgb(background), _vp), float(znear),
+                                              float(zfar), _ptr(gcol), _ptr(gd), _ptr(gz, None, True),
+                                              _stream(colors)), "ur_blend_colors_backward")
+    return gcol, gd, gz
 
 
 def render_layered_forward(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_radius, faces_per_pixel,

@@ -72,6 +72,34 @@ class _ShadeBlend(Function):
                 None, None, None)
 
 
+class _BlendColors(Function):
+    """ur_blend_colors / ur_blend_colors_backward: layered or softmax blending of caller-computed fragment colours."""
+
+    @staticmethod
+    def forward(ctx, colors, dists, zbuf, p2f, kind, sigma, gamma, background, znear, zfar):
+        colors, dists = colors.contiguous(), dists.contiguous()
+        zbuf = None if zbuf is None else zbuf.contiguous()
+        ctx.save_for_backward(colors, dists, zbuf, p2f)
+        ctx.cfg = (kind, sigma, gamma, background, znear, zfar)
+        return native.blend_colors(colors, p2f, dists, zbuf, kind, sigma, gamma, background, znear, zfar)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_image):
+        colors, dists, zbuf, p2f = ctx.saved_tensors
+        kind, sigma, gamma, background, znear, zfar = ctx.cfg
+        gcol, gd, gz = native.blend_colors_backward(grad_image.contiguous(), colors, p2f, dists, zbuf, kind, sigma,
+                                                    gamma, background, znear, zfar)
+        need = ctx.needs_input_grad
+        return (gcol if need[0] else None, gd if need[1] else None, gz if (need[2] and zbuf is not None) else None,
+                None, None, None, None, None, None, None)
+
+
+def blend_colors(colors, p2f, dists, zbuf, kind, sigma, gamma, background, znear=1.0, zfar=100.0):
+    return _BlendColors.apply(colors, dists, zbuf, p2f, int(kind), float(sigma), float(gamma), tuple(background),
+                              float(znear), float(zfar))
+
+
 class _RenderLayered(Function):
     """ur_render_layered_forward / _backward: rasterize + sample + blend in one launch each way."""
 

@@ -11,7 +11,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import native, ops
+from . import lighting, native, ops
 from .cameras import FoVPerspectiveCameras, PerspectiveCameras
 from .structures import Meshes, TexturesUV, TexturesVertex  # noqa: F401  (re-exported for callers)
 
@@ -146,9 +146,8 @@ class LayeredShader(nn.Module):
         self.clip_inside, self.shading_type, self.debug = clip_inside, shading_type, debug
         if shading_type not in ('raw', 'phong', 'flat', 'gouraud'):
             raise NotImplementedError
-        if shading_type != 'raw':
-            raise NotImplementedError("only shading_type='raw' (the training setting, renderer.py:21) is built; "
-                                      "phong/flat/gouraud serve the eye_light GIF viz only")
+        if self.materials is None:
+            self.materials = lighting.Materials()
         if debug:
             raise NotImplementedError("debug=True returns the blend's intermediates; not built")
 
@@ -178,14 +177,59 @@ class LayeredShader(nn.Module):
     def forward(self, fragments, meshes, **kwargs):
         bp = kwargs.get("blend_params", self.blend_params)
         tex = meshes.textures
-        if not isinstance(tex, TexturesUV):
-            raise NotImplementedError("LayeredShader needs TexturesUV (TexturesVertex: see shading.sample_textures)")
+        if self.shading_type != 'raw' or not isinstance(tex, TexturesUV):
+            # lit colours (renderer.py:165-171) or vertex colours, then layered_rgb_blend over them (ur_blend_colors)
+            colors = lit_colors(self.shading_type, meshes, fragments, kwargs.get("lights", self.lights),
+                                kwargs.get("materials", self.materials), kwargs["R"], kwargs["T"])
+            return ops.blend_colors(colors, fragments.pix_to_face_i32, fragments.dists, None, self.blend_mode(bp),
+                                    bp.sigma, bp.gamma, _rgb3(bp.background_color))
         ambient = _rgb3(self.lights.ambient_color)
         face_uvs, shared = tex.faces_verts_uvs()
         return ops.shade_blend(fragments.pix_to_face_i32, fragments.bary_coords, fragments.dists,
                                tex.maps_padded().float(), face_uvs.float(), shared, fragments.mesh_first_face,
                                bp.sigma, _rgb3(bp.background_color), None if ambient == (1.0, 1.0, 1.0) else ambient,
                                self.blend_mode(bp))
+
+
+def lit_colors(shading_type, meshes, fragments, lights, materials, R, T):
+    """per-fragment colours (N,H,W,K,3) of LayeredShader's / SoftPhongShader's shading step"""
+    if shading_type == 'gouraud':
+        return lighting.gouraud_shading(meshes, fragments, lights, materials, R, T)
+    texels = meshes.sample_textures(fragments)
+    if shading_type == 'raw':
+        amb = torch.as_tensor(lights.ambient_color, dtype=torch.float32, device=texels.device)
+        return texels if bool(torch.all(amb == 1)) else texels * amb.view(-1, 1, 1, 1, 3)  # renderer.py:162-164
+    fn = {'phong': lighting.phong_shading, 'flat': lighting.flat_shading}[shading_type]
+    return fn(meshes, fragments, lights, materials, texels, R, T)
+
+
+class SoftPhongShaderPlus(nn.Module):
+    """Reference: SoftPhongShaderPlus (renderer.py:205-216) = pytorch3d SoftPhongShader (phong_shading +
+    softmax_rgb_blend with the cameras' znear / zfar, defaults 1 / 100) with a BCHW output."""
+
+    def __init__(self, device='cpu', cameras=None, lights=None, materials=None, blend_params=None, debug=False):
+        super().__init__()
+        self.lights = lights if lights is not None else PointLights()
+        self.materials = materials if materials is not None else lighting.Materials()
+        self.cameras = cameras
+        self.blend_params = blend_params if blend_params is not None else BlendParams()
+
+    def to(self, device):
+        if self.cameras is not None:
+            self.cameras = self.cameras.to(device)
+        self.lights = self.lights.to(device)
+        self.materials = self.materials.to(device)
+        return self
+
+    def forward(self, fragments, meshes, **kwargs):
+        bp = kwargs.get("blend_params", self.blend_params)
+        cams = kwargs.get("cameras", self.cameras)
+        colors = lit_colors('phong', meshes, fragments, kwargs.get("lights", self.lights),
+                            kwargs.get("materials", self.materials), kwargs["R"], kwargs["T"])
+        znear = kwargs.get("znear", getattr(cams, "znear", 1.0))
+        zfar = kwargs.get("zfar", getattr(cams, "zfar", 100.0))
+        return ops.blend_colors(colors, fragments.pix_to_face_i32, fragments.dists, fragments.zbuf,
+                                native.BLEND_SOFTMAX, bp.sigma, bp.gamma, _rgb3(bp.background_color), znear, zfar)
 
 
 class MeshRenderer(nn.Module):
@@ -203,7 +247,8 @@ class MeshRenderer(nn.Module):
         return self
 
     def forward(self, meshes, **kwargs):
-        if self.fused and isinstance(self.shader, LayeredShader) and isinstance(meshes.textures, TexturesUV):
+        if self.fused and isinstance(self.shader, LayeredShader) and self.shader.shading_type == 'raw' \
+                and isinstance(meshes.textures, TexturesUV):
             return self.shader.render_fused(self.rasterizer, meshes, **kwargs)
         fragments = self.rasterizer(meshes, **kwargs)
         return self.shader(fragments, meshes, **kwargs)
@@ -236,7 +281,7 @@ class Renderer(nn.Module):
             s_kwargs['clip_inside'] = kwargs.get('clip_inside', True)
             s_kwargs['shading_type'] = kwargs.get('shading_type', SHADING_TYPE)
         else:
-            raise NotImplementedError("layered_shader=False (SoftPhongShaderPlus / softmax blend) is not built yet")
+            shader_cls = SoftPhongShaderPlus
 
         # approximative differentiable renderer for training (renderer.py:45-49)
         raster_settings = RasterizationSettings(image_size=img_size,

@@ -236,6 +236,23 @@ class Meshes:
     def faces_packed_to_mesh_idx(self):
         return torch.repeat_interleave(torch.arange(self._N, device=self.device), self.num_faces_per_mesh())
 
+    def faces_normals_packed(self):
+        """unit face normals (NF,3): normalize(cross(v1 - v0, v2 - v0), eps=1e-6) (pytorch3d Meshes)"""
+        fv = self.verts_packed()[self.faces_packed()]
+        n = torch.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0], dim=1)
+        return torch.nn.functional.normalize(n, eps=1e-6, dim=1)
+
+    def verts_normals_packed(self):
+        """area-weighted vertex normals (V,3): every face adds the cross product of its two edges at each corner,
+        then normalize(eps=1e-6) (pytorch3d Meshes._compute_vertex_normals)"""
+        verts, faces = self.verts_packed(), self.faces_packed()
+        fv = verts[faces]
+        out = torch.zeros_like(verts)
+        out = out.index_add(0, faces[:, 1], torch.cross(fv[:, 2] - fv[:, 1], fv[:, 0] - fv[:, 1], dim=1))
+        out = out.index_add(0, faces[:, 2], torch.cross(fv[:, 0] - fv[:, 2], fv[:, 1] - fv[:, 2], dim=1))
+        out = out.index_add(0, faces[:, 0], torch.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0], dim=1))
+        return torch.nn.functional.normalize(out, eps=1e-6, dim=1)
+
     def get_mesh_verts_faces(self, index):
         return self.verts_list()[index], self.faces_list()[index]
 
