@@ -155,6 +155,20 @@ int ur_blend_colors_backward(const float* grad_image, const float* colors, const
                              float* grad_dists, float* grad_zbuf, void* stream);
 
 /*
+ * Mesh regularisers of the 3D step, value and gradient in one launch (one workgroup per mesh, shared topology).
+ * Replaces: normal_consistency(meshes) (utils/mesh.py:92-139, the icosphere / shared-topology routine) and pytorch3d's
+ *           mesh_laplacian_smoothing(meshes, method='uniform'), both called at unicorn.py:340-343, and their autograd.
+ *   verts (N,V,3) ; edge_quads (E,4) int32, 16-byte aligned: (v0, v1, a, b) = an edge and the third vertex of each of
+ *   its two faces (closed manifold) ; nbr_offsets (V+1) / nbr_index: vertex adjacency in CSR form ;
+ *   normal_sum[n] = sum_e 1 - cos(n0, n1) ; laplacian_sum[n] = sum_i || mean_{j in N(i)} v_j - v_i || ;
+ *   grad_normal / grad_laplacian (N,V,3): their gradients w.r.t. verts (either may be NULL) ; scratch (N,V,3) floats.
+ * The reference's means are normal_sum.sum() / (N E) and (laplacian_sum / V).sum() / N.
+ */
+int ur_mesh_regularizers(const float* verts, int N, int V, const int32_t* edge_quads, int E, const int32_t* nbr_offsets,
+                         const int32_t* nbr_index, float* normal_sum, float* laplacian_sum, float* grad_normal,
+                         float* grad_laplacian, float* scratch, void* stream);
+
+/*
  * Fused training path: rasterize + UV-sample + layered blend in ONE launch, and its backward in ONE launch.
  * Replaces: MeshRenderer.forward = MeshRasterizer (renderer.py:48) + LayeredShader.forward (renderer.py:159-172) and
  *           the autograd of both (trainer.py:151).  Numerically identical to ur_rasterize_meshes + ur_shade_blend:

@@ -192,6 +192,18 @@ def softmax_blend_bwd(colors, pix_to_face, dists, zbuf, grad_image, sigma, gamma
     return gcol, gds, gzb
 
 
+def mesh_regularizers(verts, edge_quads, nbr_offsets, nbr_index, dtype=np.float32):
+    """-> per-mesh sums (normal, laplacian) and their gradients (N,V,3)"""
+    v = _c(verts, dtype)
+    q, off, idx = _c(edge_quads, np.int32), _c(nbr_offsets, np.int32), _c(nbr_index, np.int32)
+    N, V = v.shape[:2]
+    nsum, lsum = np.empty(N, dtype), np.empty(N, dtype)
+    gN, gL = np.empty_like(v), np.empty_like(v)
+    getattr(lib(), "orc_mesh_regularizers_" + _sfx(dtype))(_p(v), N, V, _p(q), q.shape[0], _p(off), _p(idx), _p(nsum),
+                                                          _p(lsum), _p(gN), _p(gL))
+    return nsum, lsum, gN, gL
+
+
 def render_fwd_bwd(verts, faces, R, T, maps, verts_uvs, H, W, K, s, sigma=1e-4, background=(1., 1., 1.),
                    clip_inside=True, grad_image=None, n_threads=1, blur_radius=None, dtype=np.float32):
     """Whole path on the CPU.  verts (N,V,3), faces (F,3) shared topology, maps (N,Ht,Wt,3), verts_uvs (N,V,2).

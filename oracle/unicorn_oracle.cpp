@@ -661,6 +661,83 @@ void softmax_blend_bwd(const T* colors, const int64_t* pix_to_face, const T* dis
 }
 
 // ---------------------------------------------------------------------------------------------
+// mesh regularisers of the 3D step (unicorn.py:338-343), shared topology:
+//   normal consistency   utils/mesh.py:92-139: per edge, 1 - cosine_similarity(n0, n1) with n0 = (v1-v0) x (a-v0),
+//                        n1 = -((v1-v0) x (b-v0)), a / b the third vertices of the edge's two faces
+//                        (torch.cosine_similarity: dot / (max(|x|, 1e-8) max(|y|, 1e-8)))
+//   uniform Laplacian    pytorch3d mesh_laplacian_smoothing(method='uniform'): || mean_{j in N(i)} v_j - v_i ||
+// Per mesh sums and their gradients w.r.t. verts.  Pinned by tests/golden/regularizers.npz (the normal term by the
+// reference's own function, the Laplacian by a float64 torch restatement).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+void mesh_regularizers(const T* verts, int N, int V, const int32_t* quads, int E, const int32_t* off, const int32_t* idx,
+                       T* nsum, T* lsum, T* gN, T* gL) {
+  auto cross = [](const T* a, const T* b, T* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  const T eps = T(1e-8);
+  for (int n = 0; n < N; ++n) {
+    const T* vp = verts + (int64_t)n * V * 3;
+    T* gn = gN + (int64_t)n * V * 3;
+    T* gl = gL + (int64_t)n * V * 3;
+    std::fill(gn, gn + V * 3, T(0));
+    T ns = T(0), ls = T(0);
+    for (int e = 0; e < E; ++e) {
+      const int32_t* q = quads + 4 * e;
+      T ev[3], pa[3], pb[3], n0[3], n1[3];
+      for (int c = 0; c < 3; ++c) {
+        ev[c] = vp[q[1] * 3 + c] - vp[q[0] * 3 + c];
+        pa[c] = vp[q[2] * 3 + c] - vp[q[0] * 3 + c];
+        pb[c] = vp[q[3] * 3 + c] - vp[q[0] * 3 + c];
+      }
+      cross(ev, pa, n0);
+      cross(pb, ev, n1);
+      const T l0 = std::sqrt(n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]);
+      const T l1 = std::sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+      const T m0 = std::max(l0, eps), m1 = std::max(l1, eps);
+      const T cs = (n0[0] * n1[0] + n0[1] * n1[1] + n0[2] * n1[2]) / (m0 * m1);
+      ns += T(1) - cs;
+      T g0[3], g1[3], ge[3], gpa[3], gpb[3], t[3];
+      for (int c = 0; c < 3; ++c) {
+        g0[c] = -(n1[c] / (m0 * m1) - (l0 > eps ? cs * n0[c] / (m0 * m0) : T(0)));
+        g1[c] = -(n0[c] / (m0 * m1) - (l1 > eps ? cs * n1[c] / (m1 * m1) : T(0)));
+      }
+      cross(pa, g0, ge);
+      cross(g1, pb, t);
+      cross(g0, ev, gpa);
+      cross(ev, g1, gpb);
+      for (int c = 0; c < 3; ++c) {
+        ge[c] += t[c];
+        gn[q[0] * 3 + c] -= ge[c] + gpa[c] + gpb[c];
+        gn[q[1] * 3 + c] += ge[c];
+        gn[q[2] * 3 + c] += gpa[c];
+        gn[q[3] * 3 + c] += gpb[c];
+      }
+    }
+    std::vector<T> u((size_t)V * 3);
+    for (int i = 0; i < V; ++i) {
+      T sacc[3] = {0, 0, 0};
+      for (int j = off[i]; j < off[i + 1]; ++j)
+        for (int c = 0; c < 3; ++c) sacc[c] += vp[idx[j] * 3 + c];
+      const T inv = off[i + 1] > off[i] ? T(1) / T(off[i + 1] - off[i]) : T(0);
+      T lv[3];
+      for (int c = 0; c < 3; ++c) lv[c] = sacc[c] * inv - vp[i * 3 + c];
+      const T r = std::sqrt(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
+      ls += r;
+      for (int c = 0; c < 3; ++c) u[(size_t)i * 3 + c] = r > T(0) ? lv[c] / r : T(0);
+    }
+    for (int i = 0; i < V; ++i)
+      for (int c = 0; c < 3; ++c) {
+        T g = -u[(size_t)i * 3 + c];
+        for (int j = off[i]; j < off[i + 1]; ++j) g += u[(size_t)idx[j] * 3 + c] / T(off[idx[j] + 1] - off[idx[j]]);
+        gl[i * 3 + c] = g;
+      }
+    nsum[n] = ns;
+    lsum[n] = ls;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // render_fwd_bwd: the whole path for one batch (CPU baseline of bench.py and end-to-end parity):
 // project -> gather faces -> rasterize -> sample -> layered blend, then the backward of all of it
 // for a given cotangent grad_image.  Meshes share one face topology (F,3); mesh n of the call uses
@@ -779,6 +856,11 @@ template <typename T> void render_fwd_bwd(const RenderArgs<T>& a, int n_threads)
                                               int H, int W, int K, T sigma, T gamma, const T* bg, T znear, T zfar,    \
                                               T* image) {                                                             \
     softmax_blend_fwd<T>(col, p2f, ds, zb, N, H, W, K, sigma, gamma, bg, znear, zfar, image);                         \
+  }                                                                                                                   \
+  extern "C" void orc_mesh_regularizers_##SFX(const T* verts, int N, int V, const int32_t* quads, int E,              \
+                                              const int32_t* off, const int32_t* idx, T* nsum, T* lsum, T* gN,        \
+                                              T* gL) {                                                                \
+    mesh_regularizers<T>(verts, N, V, quads, E, off, idx, nsum, lsum, gN, gL);                                        \
   }                                                                                                                   \
   extern "C" void orc_softmax_blend_bwd_##SFX(const T* col, const int64_t* p2f, const T* ds, const T* zb,             \
                                               const T* gimg, int N, int H, int W, int K, T sigma, T gamma,            \

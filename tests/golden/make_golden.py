@@ -11,6 +11,11 @@ What is pinned here, and by what:
                       (reached from renderer.py:162) -- forward and autograd backward.
   G3 helpers.npz      convert_3d_to_uv_coordinates, azim/elev/roll_to_rotation_matrix (src/model/tools.py:164-171,
                       197-231), AST-extracted the same way; pins unicorn_amd/synth.py.
+  G4 regularizers.npz the reference's own `normal_consistency` (src/utils/mesh.py:92-139, icosphere / shared-topology
+                      routine), AST-extracted and run on a duck-typed meshes object (verts / faces / edge tables are
+                      fixture INPUTS, built by unicorn_amd.structures.Meshes on the CPU), value and autograd gradient;
+                      plus the uniform Laplacian of pytorch3d's mesh_laplacian_smoothing RESTATED in float64 torch
+                      (pytorch3d is absent: that half is not a reference output, parity unpinned).
 Nothing of the reference's text is written to the fixtures: they hold inputs and outputs only.
 """
 import ast
@@ -98,7 +103,43 @@ def make_helpers():
              R_azim=az_fn(ang[0]).numpy(), R_elev=el_fn(ang[1]).numpy(), R_roll=ro_fn(ang[2]).numpy(), R=R.numpy())
 
 
+def make_regularizers():
+    import sys
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from unicorn_amd import synth
+    from unicorn_amd.structures import Meshes
+    (nc,) = extract("/root/reference/src/utils/mesh.py", ["normal_consistency"],
+                    {"torch": torch, "mesh_normal_consistency": None})
+    sc = synth.make_scene(3, level=2, tex_size=8, seed=11)
+    verts = (sc["verts"].double() + 0.03 * torch.randn(sc["verts"].shape, generator=torch.Generator().manual_seed(3),
+                                                       dtype=torch.float64)).requires_grad_(True)
+    N, V = verts.shape[:2]
+    faces = sc["faces"]
+    m = Meshes(verts=verts, faces=faces[None].expand(N, -1, -1))
+    duck = types.SimpleNamespace(isempty=lambda: False, device=verts.device, verts_packed=m.verts_packed,
+                                 faces_packed=m.faces_packed, edges_packed=m.edges_packed,
+                                 verts_packed_to_mesh_idx=m.verts_packed_to_mesh_idx,
+                                 faces_packed_to_edges_packed=m.faces_packed_to_edges_packed)
+    duck_cls = type("Duck", (), {"__len__": lambda self: N, "__getattr__": lambda self, k: getattr(duck, k)})
+    loss = nc(duck_cls())
+    (g_nc,) = torch.autograd.grad(loss, verts)
+    # uniform Laplacian, restated: L v_i = mean_{j in N(i)} v_j - v_i ; loss = mean over meshes of mean_i ||L v_i||
+    e = m.edges_packed()
+    Vt = N * V
+    A = torch.zeros(Vt, Vt, dtype=torch.float64)
+    A[e[:, 0], e[:, 1]] = 1.0
+    A[e[:, 1], e[:, 0]] = 1.0
+    deg = A.sum(1, keepdim=True)
+    Lv = (A / deg) @ m.verts_packed() - m.verts_packed()
+    lap = (Lv.norm(dim=1) / V).sum() / N
+    (g_lap,) = torch.autograd.grad(lap, verts)
+    np.savez(os.path.join(OUT, "regularizers.npz"), verts=verts.detach().numpy(), faces=faces.numpy(),
+             edges_packed=e.numpy(), faces_to_edges=m.faces_packed_to_edges_packed().numpy(),
+             normal=loss.item(), grad_normal=g_nc.numpy(), laplacian=lap.item(), grad_laplacian=g_lap.numpy())
+
+
 if __name__ == "__main__":
+    make_regularizers()
     make_blend()
     make_uvsample()
     make_helpers()

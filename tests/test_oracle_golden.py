@@ -104,3 +104,19 @@ def test_softmax_blend_matches_torch_autograd():
     np.testing.assert_allclose(gc, tc.grad.numpy(), atol=1e-13)
     np.testing.assert_allclose(gd, td.grad.numpy(), rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(gz, tz.grad.numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_mesh_regularizers_match_reference_golden(golden_dir):
+    """normal term: the reference's own normal_consistency (utils/mesh.py:92-139) run by tests/golden/make_golden.py;
+    Laplacian: float64 torch restatement of pytorch3d's uniform mesh_laplacian_smoothing (parity unpinned)."""
+    from unicorn_amd.regularizers import build_topology
+    g = np.load(os.path.join(golden_dir, "regularizers.npz"))
+    quads, off, idx = build_topology(g["faces"])
+    N, V = g["verts"].shape[:2]
+    E = quads.shape[0]
+    assert E == g["edges_packed"].shape[0] // N and off[-1] == 2 * E
+    nsum, lsum, gN, gL = orc.mesh_regularizers(g["verts"], quads, off, idx, dtype=np.float64)
+    np.testing.assert_allclose(nsum.sum() / (N * E), g["normal"], rtol=1e-12)
+    np.testing.assert_allclose(gN / (N * E), g["grad_normal"], atol=1e-12)
+    np.testing.assert_allclose(lsum.sum() / (N * V), g["laplacian"], rtol=1e-12)
+    np.testing.assert_allclose(gL / (N * V), g["grad_laplacian"], atol=1e-12)

@@ -1858,6 +1858,131 @@ __global__ void __launch_bounds__(256) k_blend_bwd(const BlendParamsK P) {
   if (P.gzbuf && zraw >= kSoftEps && P.p2f[base + kmax] >= 0) P.gzbuf[base + kmax] += -g_zmax / zden;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// mesh regularisers of the 3D step (unicorn.py:338-343): normal consistency over edges (utils/mesh.py:92-139) and the
+// uniform Laplacian (pytorch3d mesh_laplacian_smoothing(method='uniform')), value AND gradient in one launch.
+// One workgroup per mesh; all meshes share one topology (edge table + vertex adjacency, built once on the host).
+//   edge table row = (v0, v1, a, b): the edge and the third vertex of each of its two faces
+//   normal term    = sum_e 1 - cos(n0, n1), n0 = (v1-v0) x (a-v0), n1 = -((v1-v0) x (b-v0)), cos with norms clamped at 1e-8
+//   laplacian term = sum_i || mean_{j in N(i)} v_j - v_i ||
+// Edge gradients are summed per vertex in an f64 LDS table when V*24 B fit (no global atomics), else float atomics.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ void __launch_bounds__(1024) k_mesh_reg(const float* __restrict__ verts, int V, const int4* __restrict__ quads,
+                                                   int E, const int* __restrict__ nbr_off, const int* __restrict__ nbr_idx,
+                                                   float* __restrict__ nsum, float* __restrict__ lsum,
+                                                   float* __restrict__ gN, float* __restrict__ gL,
+                                                   float* __restrict__ scratch, int lds_acc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* part = reinterpret_cast<float*>(smem);          // 2 x 16 wave partial sums
+  double* acc = reinterpret_cast<double*>(smem + 128);   // V*3 when lds_acc
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* vp = verts + (int64_t)n * V * 3;
+  float* gn = gN ? gN + (int64_t)n * V * 3 : nullptr;
+  float* gl = gL ? gL + (int64_t)n * V * 3 : nullptr;
+  float* u = scratch + (int64_t)n * V * 3;
+  if (gn) {
+    if (lds_acc) for (int i = tid; i < V * 3; i += 1024) acc[i] = 0.0;
+    else for (int i = tid; i < V * 3; i += 1024) gn[i] = 0.0f;
+  }
+  __syncthreads();
+  // ---- normal consistency
+  float nloss = 0.0f;
+  for (int e = tid; e < E; e += 1024) {
+    const int4 q = quads[e];
+    float v0[3], ev[3], pa[3], pb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      v0[c] = vp[q.x * 3 + c];
+      ev[c] = vp[q.y * 3 + c] - v0[c];
+      pa[c] = vp[q.z * 3 + c] - v0[c];
+      pb[c] = vp[q.w * 3 + c] - v0[c];
+    }
+    float n0[3], n1[3];
+    cross3(ev, pa, n0);
+    cross3(pb, ev, n1);  // = -(e x pb)
+    const float l0 = sqrtf(n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]);
+    const float l1 = sqrtf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+    const float m0 = max_s(l0, 1e-8f), m1 = max_s(l1, 1e-8f);
+    const float dot = n0[0] * n1[0] + n0[1] * n1[1] + n0[2] * n1[2];
+    const float cs = dot / (m0 * m1);
+    nloss += 1.0f - cs;
+    if (gn) {
+      // d(1 - cos)/dn0 = -(n1/(m0 m1) - cos n0/m0^2 [if l0 > eps]), likewise n1
+      float g0[3], g1[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        g0[c] = -(n1[c] / (m0 * m1) - (l0 > 1e-8f ? cs * n0[c] / (m0 * m0) : 0.0f));
+        g1[c] = -(n0[c] / (m0 * m1) - (l1 > 1e-8f ? cs * n1[c] / (m1 * m1) : 0.0f));
+      }
+      // n0 = e x pa: d/de = pa x g0, d/dpa = g0 x e ; n1 = pb x e: d/dpb = e x g1, d/de = g1 x pb
+      float ge[3], gpa[3], gpb[3], t[3];
+      cross3(pa, g0, ge);
+      cross3(g1, pb, t);
+      cross3(g0, ev, gpa);
+      cross3(ev, g1, gpb);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        ge[c] += t[c];
+        const float gv0 = -(ge[c] + gpa[c] + gpb[c]);
+        if (lds_acc) {
+          atomicAdd(&acc[q.x * 3 + c], (double)gv0); atomicAdd(&acc[q.y * 3 + c], (double)ge[c]);
+          atomicAdd(&acc[q.z * 3 + c], (double)gpa[c]); atomicAdd(&acc[q.w * 3 + c], (double)gpb[c]);
+        } else {
+          atomicAdd(&gn[q.x * 3 + c], gv0); atomicAdd(&gn[q.y * 3 + c], ge[c]);
+          atomicAdd(&gn[q.z * 3 + c], gpa[c]); atomicAdd(&gn[q.w * 3 + c], gpb[c]);
+        }
+      }
+    }
+  }
+  // ---- uniform Laplacian: pass 1, u_i = Lv_i / ||Lv_i|| parked in scratch
+  float lloss = 0.0f;
+  for (int i = tid; i < V; i += 1024) {
+    const int b = nbr_off[i], e = nbr_off[i + 1];
+    float s[3] = {0.0f, 0.0f, 0.0f};
+    for (int j = b; j < e; ++j) {
+      const int k = nbr_idx[j];
+      s[0] += vp[k * 3 + 0]; s[1] += vp[k * 3 + 1]; s[2] += vp[k * 3 + 2];
+    }
+    const float inv = e > b ? 1.0f / (float)(e - b) : 0.0f;
+    float lv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lv[c] = s[c] * inv - vp[i * 3 + c];
+    const float r = sqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
+    lloss += r;
+    const float ir = r > 0.0f ? 1.0f / r : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u[i * 3 + c] = lv[c] * ir;
+  }
+  // block sums
+  const float wn = wave_sum(nloss), wl = wave_sum(lloss);
+  if ((tid & 63) == 63) { part[tid >> 6] = wn; part[16 + (tid >> 6)] = wl; }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.0f, b = 0.0f;
+    for (int w = 0; w < 16; ++w) { a += part[w]; b += part[16 + w]; }
+    nsum[n] = a;
+    lsum[n] = b;
+  }
+  // ---- pass 2: d/dv_i sum_k ||Lv_k|| = sum_{j in N(i)} u_j / deg_j - u_i  (adjacency is symmetric)
+  if (gl)
+    for (int i = tid; i < V; i += 1024) {
+      float g[3] = {-u[i * 3 + 0], -u[i * 3 + 1], -u[i * 3 + 2]};
+      for (int j = nbr_off[i]; j < nbr_off[i + 1]; ++j) {
+        const int k = nbr_idx[j];
+        const float inv = 1.0f / (float)(nbr_off[k + 1] - nbr_off[k]);
+        g[0] += u[k * 3 + 0] * inv; g[1] += u[k * 3 + 1] * inv; g[2] += u[k * 3 + 2] * inv;
+      }
+      gl[i * 3 + 0] = g[0]; gl[i * 3 + 1] = g[1]; gl[i * 3 + 2] = g[2];
+    }
+  if (gn && lds_acc)
+    for (int i = tid; i < V * 3; i += 1024) gn[i] = (float)acc[i];
+}
+
 int fill_blend_params(BlendParamsK& P, const float* colors, const int32_t* p2f, const float* dists, const float* zbuf,
                       int N, int H, int W, int K, int kind, float sigma, float gamma, const float* bg, float znear,
                       float zfar) {
@@ -2075,6 +2200,30 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
   if (lds > 64 * 1024) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d too large for the blend backward", K);
   hipLaunchKernelGGL(k_shade_bwd, dim3((unsigned)((npix + 63) / 64)), dim3(64), lds, (hipStream_t)stream, P);
   return check_launch("k_shade_bwd");
+}
+
+int ur_mesh_regularizers(const float* verts, int N, int V, const int32_t* edge_quads, int E, const int32_t* nbr_offsets,
+                         const int32_t* nbr_index, float* normal_sum, float* laplacian_sum, float* grad_normal,
+                         float* grad_laplacian, float* scratch, void* stream) {
+  if (!verts || !edge_quads || !nbr_offsets || !nbr_index || !normal_sum || !laplacian_sum || !scratch)
+    return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || V <= 0 || E < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (reinterpret_cast<uintptr_t>(edge_quads) & 15) return fail(UR_ERR_INVALID_ARG, "edge table must be 16-byte aligned");
+  if (N == 0) return UR_OK;
+  const size_t lds_full = 128 + (size_t)V * 3 * 8;
+  const int lds_acc = lds_full <= 150 * 1024;
+  const size_t lds = lds_acc ? lds_full : 128;
+  static thread_local size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mesh_reg),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_mesh_reg, dim3((unsigned)N), dim3(1024), lds, (hipStream_t)stream, verts, V,
+                     reinterpret_cast<const int4*>(edge_quads), E, nbr_offsets, nbr_index, normal_sum, laplacian_sum,
+                     grad_normal, grad_laplacian, scratch, lds_acc);
+  return check_launch("k_mesh_reg");
 }
 
 int ur_blend_colors(const float* colors, const int32_t* pix_to_face, const float* dists, const float* zbuf, int N,

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "ur_blend_colors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _f, _f, _vp, _vp]),
     "ur_blend_colors_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _f, _f, _vp, _vp, _vp,
                                       _vp]),
+    "ur_mesh_regularizers": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ur_layers_elems": (_sz, [_i, _i, _i, _i]),
     "ur_selftest_division": (_i, [ctypes.c_uint64, ctypes.c_uint32, _vp, _vp]),
     "ur_render_layered_forward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
@@ -345,6 +346,24 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
             _ptr(gfv, None, True),
             _ptr(gmaps, None, True), _stream(maps)), "ur_render_layered_backward")
     return gfv, gmaps
+
+
+def mesh_regularizers(verts, edge_quads, nbr_offsets, nbr_index, need_grad=True):
+    """verts (N,V,3) -> per-mesh sums (normal, laplacian) and, when asked, their gradients (N,V,3) each"""
+    N, V = verts.shape[:2]
+    dev = verts.device
+    nsum = torch.empty(N, dtype=torch.float32, device=dev)
+    lsum = torch.empty(N, dtype=torch.float32, device=dev)
+    gN = torch.empty_like(verts) if need_grad else None
+    gL = torch.empty_like(verts) if need_grad else None
+    scratch = torch.empty_like(verts)
+    with _on(verts), _timed("ur_mesh_regularizers", verts):
+        _check(lib().ur_mesh_regularizers(_ptr(verts, torch.float32), N, V, _ptr(edge_quads, torch.int32),
+                                          int(edge_quads.shape[0]), _ptr(nbr_offsets, torch.int32),
+                                          _ptr(nbr_index, torch.int32), _ptr(nsum), _ptr(lsum), _ptr(gN, None, True),
+                                          _ptr(gL, None, True), _ptr(scratch), _stream(verts)),
+               "ur_mesh_regularizers")
+    return nsum, lsum, gN, gL
 
 
 def profile_begin(max_launches):

@@ -1,0 +1,96 @@
+"""Mesh regularisers of the 3D step (unicorn.py:338-343) on the HIP kernel `ur_mesh_regularizers`: value and gradient of
+both terms in ONE launch, one workgroup per mesh.
+
+    normal_consistency(meshes)                      reference: utils/mesh.py:92-139 (icosphere / shared topology)
+    laplacian_smoothing(meshes, method='uniform')   reference: pytorch3d mesh_laplacian_smoothing, unicorn.py:343
+    mesh_regularizers(meshes) -> (normal, laplacian)   both from the same launch
+
+All meshes of the batch must share one closed-manifold face topology (the reference deforms one icosphere,
+unicorn.py:88-93,283); the edge table and the vertex adjacency are built once per faces tensor and cached.
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import native
+
+_topo_cache = {}
+
+
+def build_topology(faces):
+    """faces (F,3) int -> edge_quads (E,4) int32 rows (v0, v1, a, b), nbr_offsets (V+1), nbr_index: numpy arrays"""
+    f = np.asarray(faces, dtype=np.int64)
+    V = int(f.max()) + 1
+    # the three directed edges of every face with the face's third vertex
+    ed = np.concatenate([f[:, [0, 1, 2]], f[:, [1, 2, 0]], f[:, [2, 0, 1]]], 0)  # (3F, 3): (p, q, opposite)
+    lo, hi = np.minimum(ed[:, 0], ed[:, 1]), np.maximum(ed[:, 0], ed[:, 1])
+    key = lo * V + hi
+    order = np.argsort(key, kind="stable")
+    key, lo, hi, opp = key[order], lo[order], hi[order], ed[order, 2]
+    uniq, counts = np.unique(key, return_counts=True)
+    if not (counts == 2).all():
+        raise ValueError("normal consistency needs a closed manifold mesh: every edge must belong to exactly two faces")
+    quads = np.stack([lo[0::2], hi[0::2], opp[0::2], opp[1::2]], 1).astype(np.int32)
+    # vertex adjacency (CSR), from the unique edges in both directions
+    src = np.concatenate([quads[:, 0], quads[:, 1]])
+    dst = np.concatenate([quads[:, 1], quads[:, 0]])
+    o = np.argsort(src, kind="stable")
+    offsets = np.zeros(V + 1, np.int32)
+    np.cumsum(np.bincount(src, minlength=V), out=offsets[1:])
+    return quads, offsets, dst[o].astype(np.int32)
+
+
+def _topology(faces):
+    key = (faces.data_ptr(), faces._version, tuple(faces.shape), str(faces.device))
+    hit = _topo_cache.get(key)
+    if hit is None:
+        if len(_topo_cache) > 8:
+            _topo_cache.clear()
+        quads, off, idx = build_topology(faces.detach().cpu().numpy())
+        dev = faces.device
+        hit = _topo_cache[key] = (torch.from_numpy(quads).to(dev), torch.from_numpy(off).to(dev),
+                                  torch.from_numpy(idx).to(dev), faces)  # keeps `faces` alive: the address stays ours
+    return hit[:3]
+
+
+class _MeshReg(Function):
+    @staticmethod
+    def forward(ctx, verts, quads, off, idx):
+        verts = verts.contiguous().float()
+        need = verts.requires_grad
+        nsum, lsum, gN, gL = native.mesh_regularizers(verts, quads, off, idx, need)
+        N, V, E = verts.shape[0], verts.shape[1], quads.shape[0]
+        ctx.save_for_backward(gN, gL)
+        ctx.scale = (1.0 / (N * E), 1.0 / (N * V))
+        return nsum.sum() * ctx.scale[0], lsum.sum() * ctx.scale[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_normal, g_lap):
+        gN, gL = ctx.saved_tensors
+        return gN * (g_normal * ctx.scale[0]) + gL * (g_lap * ctx.scale[1]), None, None, None
+
+
+def mesh_regularizers(meshes):
+    """-> (normal consistency, uniform Laplacian), the two scalars of unicorn.py:340-343, from one kernel launch"""
+    if meshes.isempty():
+        z = torch.zeros((), dtype=torch.float32, device=meshes.device, requires_grad=True)
+        return z, z
+    if not meshes.equisized:
+        raise NotImplementedError("meshes must share one topology")
+    faces = meshes.faces_padded()
+    if faces.stride(0) != 0 and len(meshes) > 1 and not bool((faces == faces[:1]).all()):
+        raise NotImplementedError("meshes must share one topology (utils/mesh.py:92 shared_topology=True)")
+    quads, off, idx = _topology(faces[0])
+    return _MeshReg.apply(meshes.verts_padded(), quads, off, idx)
+
+
+def normal_consistency(meshes, icosphere_topology=True, shared_topology=True):
+    return mesh_regularizers(meshes)[0]
+
+
+def laplacian_smoothing(meshes, method="uniform"):
+    if method != "uniform":
+        raise NotImplementedError("only method='uniform' (unicorn.py:343)")
+    return mesh_regularizers(meshes)[1]
