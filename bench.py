@@ -33,6 +33,8 @@ WORKLOADS = {
     "C4_B32_128x128_K50_ico3": dict(B=32, level=3, img=128, K=50, tex=64),
     "C2_B32_64x64_K50_ico3": dict(B=32, level=3, img=64, K=50, tex=64),
     "C4b_B64_128x128_K50_ico4": dict(B=64, level=4, img=128, K=50, tex=64),
+    "C2p_B192_64x64_K50_ico3": dict(B=192, level=3, img=64, K=50, tex=64),      # pose step of cfg2: 32 x 6 candidates
+    "C5_B16_256x256_K100_ico5": dict(B=16, level=5, img=256, K=100, tex=64),
 }
 
 

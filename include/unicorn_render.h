@@ -74,7 +74,8 @@ int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mes
 
 /* Backward of ur_project_faces: grad_face_verts (N*F,3,3) -> grad_verts (N,V,3), grad_R (N,3,3), grad_T (N,3).
  * The outputs are overwritten (no need to clear them); any may be NULL.  One workgroup per mesh sums per vertex in
- * LDS (no global atomics) as long as V*24 B (f64 sums) fits the LDS; larger meshes fall back to float atomics. */
+ * LDS (f64, no global atomics on grad_verts); meshes whose V*24 B exceed the LDS are split into vertex windows, one
+ * workgroup each, whose R / T sums meet by a few float atomics. */
 int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
                               const float* T, float sx, float sy, int N, int V, int F, const float* grad_face_verts,
                               float* grad_verts, float* grad_R, float* grad_T, void* stream);

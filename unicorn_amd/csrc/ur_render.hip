@@ -1549,61 +1549,6 @@ __global__ void __launch_bounds__(256) k_project_faces(const float* __restrict__
   out[i * 3 + 2] = vz;
 }
 
-__global__ void __launch_bounds__(256) k_project_faces_bwd(const float* __restrict__ verts,
-                                                           const int64_t* __restrict__ faces, int64_t fstride,
-                                                           const float* __restrict__ R, const float* __restrict__ T,
-                                                           float sx, float sy, int N, int V, int F,
-                                                           const float* __restrict__ gfv, float* __restrict__ gverts,
-                                                           float* __restrict__ gR, float* __restrict__ gT) {
-  // one block handles a slice of one mesh's face corners so that the R / T sums can be reduced in the block
-  const int n = blockIdx.y;
-  const int fc = blockIdx.x * blockDim.x + threadIdx.x;
-  float gv[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
-  if (fc < F * 3) {
-    const int64_t vi = faces[(int64_t)n * fstride + fc];
-    const float* p = verts + ((int64_t)n * V + vi) * 3;
-    const float* r = R + (int64_t)n * 9;
-    const float* t = T + (int64_t)n * 3;
-    const float* g = gfv + ((int64_t)n * F * 3 + fc) * 3;
-    const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
-    const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
-    const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
-    gv[0] = g[0] * sx / vz;
-    gv[1] = g[1] * sy / vz;
-    gv[2] = g[2] - (g[0] * sx * vx + g[1] * sy * vy) / (vz * vz);
-    pr[0] = p[0]; pr[1] = p[1]; pr[2] = p[2];
-    if (gverts) {
-      float* go = gverts + ((int64_t)n * V + vi) * 3;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float a = gv[0] * r[i * 3 + 0] + gv[1] * r[i * 3 + 1] + gv[2] * r[i * 3 + 2];
-        if (a != 0.0f) atomicAdd(go + i, a);
-      }
-    }
-  }
-  if (!gR && !gT) return;
-  // 12 sums per mesh: wave shuffle reduction, then one atomic per wave
-  float s[12];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) s[i * 3 + j] = pr[i] * gv[j];
-  s[9] = gv[0]; s[10] = gv[1]; s[11] = gv[2];
-#pragma unroll
-  for (int q = 0; q < 12; ++q) {
-    float v = s[q];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    s[q] = v;
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (gR)
-      for (int q = 0; q < 9; ++q) atomicAdd(gR + (int64_t)n * 9 + q, s[q]);
-    if (gT)
-      for (int q = 0; q < 3; ++q) atomicAdd(gT + (int64_t)n * 3 + q, s[9 + q]);
-  }
-}
-
 // One workgroup per mesh: per-corner gradients are first summed per VERTEX in LDS (the projection is linear in the
 // upstream gradient and depends on the vertex only), then every vertex is pushed through the camera once; the R / T
 // sums are reduced in the workgroup.  No global atomics; outputs are plainly stored.
@@ -1613,18 +1558,22 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
                                                                  const float* __restrict__ T, float sx, float sy,
                                                                  int V, int F, const float* __restrict__ gfv,
                                                                  float* __restrict__ gverts, float* __restrict__ gR,
-                                                                 float* __restrict__ gT) {
+                                                                 float* __restrict__ gT, int vwin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // f64 sums: the LDS adds doubles at full rate (ds_add_f64) but serialises ds_add_f32 lane by lane (~4 clk/lane)
-  double* acc = reinterpret_cast<double*>(smem);  // V*3, then 16*12 partial sums
-  float* part = reinterpret_cast<float*>(acc + (size_t)V * 3);
+  // f64 sums: the LDS adds doubles at full rate (ds_add_f64) but serialises ds_add_f32 lane by lane (~4 clk/lane).
+  // blockIdx.y selects a window of `vwin` vertices (meshes whose V*24 B exceed the LDS take several workgroups, each
+  // scanning every corner and keeping those of its window; R / T sums then meet in zero-filled outputs by atomics).
+  double* acc = reinterpret_cast<double*>(smem);  // vwin*3, then 16*12 partial sums
+  float* part = reinterpret_cast<float*>(acc + (size_t)vwin * 3);
   const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < V * 3; i += 1024) acc[i] = 0.0;
+  const int v_lo = blockIdx.y * vwin, v_hi = min(V, v_lo + vwin);
+  for (int i = tid; i < vwin * 3; i += 1024) acc[i] = 0.0;
   __syncthreads();
   const int64_t* fc = faces + (int64_t)n * fstride;
   const float* g = gfv + (int64_t)n * F * 9;
   for (int c = tid; c < F * 3; c += 1024) {
-    const int vi = (int)fc[c];
+    const int vi = (int)fc[c] - v_lo;
+    if (vi < 0 || vi >= v_hi - v_lo) continue;
     atomicAdd(&acc[vi * 3 + 0], (double)g[c * 3 + 0]);
     atomicAdd(&acc[vi * 3 + 1], (double)g[c * 3 + 1]);
     atomicAdd(&acc[vi * 3 + 2], (double)g[c * 3 + 2]);
@@ -1635,9 +1584,10 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
   float s[12];
 #pragma unroll
   for (int q = 0; q < 12; ++q) s[q] = 0.0f;
-  for (int v = tid; v < V; v += 1024) {
+  for (int v = v_lo + tid; v < v_hi; v += 1024) {
     const float* p = verts + ((int64_t)n * V + v) * 3;
-    const float g0 = (float)acc[v * 3 + 0], g1 = (float)acc[v * 3 + 1], g2 = (float)acc[v * 3 + 2];
+    const int a = (v - v_lo) * 3;
+    const float g0 = (float)acc[a + 0], g1 = (float)acc[a + 1], g2 = (float)acc[a + 2];
     const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
     const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
     const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
@@ -1663,8 +1613,10 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
   if (tid < 12) {
     float v = 0.0f;
     for (int w = 0; w < 16; ++w) v += part[w * 12 + tid];
-    if (tid < 9) { if (gR) gR[(int64_t)n * 9 + tid] = v; }
-    else if (gT) gT[(int64_t)n * 3 + tid - 9] = v;
+    float* dst = tid < 9 ? (gR ? gR + (int64_t)n * 9 + tid : nullptr) : (gT ? gT + (int64_t)n * 3 + tid - 9 : nullptr);
+    if (dst) {
+      if (gridDim.y == 1) *dst = v; else atomicAdd(dst, v);
+    }
   }
 }
 
@@ -2087,28 +2039,28 @@ int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t 
   if (!verts || !faces || !R || !T || !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
   if (N == 0 || F == 0 || (!grad_verts && !grad_R && !grad_T)) return UR_OK;
-  const size_t lds = (size_t)V * 3 * 8 + 16 * 12 * 4;
-  if (lds <= 150 * 1024) {
-    static thread_local size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_faces_bwd_mesh),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-      configured = lds;
-    }
-    hipLaunchKernelGGL(k_project_faces_bwd_mesh, dim3((unsigned)N), dim3(1024), lds, (hipStream_t)stream, verts, faces,
-                       faces_mesh_stride, R, T, sx, sy, V, F, grad_face_verts, grad_verts, grad_R, grad_T);
-    return check_launch("k_project_faces_bwd_mesh");
+  // vertex windows: as few as make a window's f64 sums fit the LDS (one for the meshes of the reference's configs up
+  // to level 4; a level-5 icosphere, 10242 vertices, takes two)
+  const int max_win = (150 * 1024 - 16 * 12 * 4) / 24;
+  const int nwin = (V + max_win - 1) / max_win;
+  const int vwin = (V + nwin - 1) / nwin;
+  const size_t lds = (size_t)vwin * 3 * 8 + 16 * 12 * 4;
+  if (N > 65535 || nwin > 65535) return fail(UR_ERR_INVALID_ARG, "too many meshes / vertices per call");
+  static thread_local size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_faces_bwd_mesh),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = lds;
   }
-  if (N > 65535) return fail(UR_ERR_INVALID_ARG, "N > 65535 meshes per call");
-  // very large meshes: float atomics into zeroed outputs
-  if (grad_verts) (void)hipMemsetAsync(grad_verts, 0, (size_t)N * V * 12, (hipStream_t)stream);
-  if (grad_R) (void)hipMemsetAsync(grad_R, 0, (size_t)N * 36, (hipStream_t)stream);
-  if (grad_T) (void)hipMemsetAsync(grad_T, 0, (size_t)N * 12, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_project_faces_bwd, dim3((unsigned)((F * 3 + 255) / 256), (unsigned)N), dim3(256), 0,
-                     (hipStream_t)stream, verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts,
-                     grad_verts, grad_R, grad_T);
-  return check_launch("k_project_faces_bwd");
+  if (nwin > 1) {
+    if (grad_R) (void)hipMemsetAsync(grad_R, 0, (size_t)N * 36, (hipStream_t)stream);
+    if (grad_T) (void)hipMemsetAsync(grad_T, 0, (size_t)N * 12, (hipStream_t)stream);
+  }
+  hipLaunchKernelGGL(k_project_faces_bwd_mesh, dim3((unsigned)N, (unsigned)nwin), dim3(1024), lds, (hipStream_t)stream,
+                     verts, faces, faces_mesh_stride, R, T, sx, sy, V, F, grad_face_verts, grad_verts, grad_R, grad_T,
+                     vwin);
+  return check_launch("k_project_faces_bwd_mesh");
 }
 
 int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
