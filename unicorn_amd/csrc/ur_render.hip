@@ -255,6 +255,7 @@ struct RasterParams {
   int clip;
   int nbx, nby;  // bins per row / column
   int cap;       // K-list slots per lane held in LDS
+  int64_t total_faces;
   const int* order;  // workgroup -> (mesh * bins + bin), heaviest bins first
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
   // outputs (fragments)
@@ -296,7 +297,7 @@ __device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n
 constexpr int kScanQ = 8;         // faces per lane per scan round
 constexpr int kBinCap = 256 * kScanQ;  // faces per scan round = bin-list entries (u16 offsets into the round)
 constexpr int kSub = 64;         // faces staged in LDS per fine step
-constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU
+constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU (see raster_cap)
 constexpr int kPreStride = 96;   // ints per wave in the pair-prefix array: 65 prefix entries, then 64 byte marks
 
 // where the per-pixel layer counts start inside `layers` (after the [group][K][6][64] records)
@@ -924,21 +925,27 @@ size_t wave_groups(int H, int W) { return (size_t)((H + 15) / 16) * ((W + 15) / 
 constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4 + 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 8 +
                                    2 * kSub * 16 + 2 * kSub * 5 * 16;
 
-// K-list slots per lane kept in LDS: all K when they fit two workgroups per CU, else what fits (the rest spills)
-int raster_cap(int K) {
-  int fit = (int)((kLdsBudget - kRasterFixedLds) / (4 * 64 * 8));
+// K-list slots per pixel kept in LDS (the rest spills to global memory).  Four workgroups per CU (40 KB each) is the
+// best trade for the headline meshes, whose per-pixel lists are short; where many small faces fall inside every
+// pixel's blur disc the lists run deep and LDS residency pays more than occupancy (measured: 5120 faces at 128^2
+// +9 % with three workgroups per CU, 20480 faces at 256^2 / K=100 +12 % with two), so the budget follows the mesh's
+// face density on the image: faces per pixel >= 0.2 -> three workgroups per CU, and two when K > 64 as well.
+int raster_cap(int64_t total_faces, int N, int H, int W, int K) {
+  const double density = (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W);
+  const size_t budget = density < 0.2 ? (size_t)kLdsBudget : (K > 64 ? (size_t)80 * 1024 : (size_t)52 * 1024);
+  const int fit = (int)((budget - kRasterFixedLds) / (4 * 64 * 8));
   return K < fit ? K : fit;
 }
 
-size_t raster_spill_bytes(int N, int H, int W, int K) {
-  const int over = K - raster_cap(K);
+size_t raster_spill_bytes(int64_t total_faces, int N, int H, int W, int K) {
+  const int over = K - raster_cap(total_faces, N, H, W, K);
   return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
 }
 
 template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
-  P.cap = (MODE == 1) ? 1 : raster_cap(P.K);
+  P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K);
   const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static thread_local size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
@@ -976,7 +983,7 @@ int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const 
   int* binload = reinterpret_cast<int*>(fz + ((NF + 3) / 4) * 4);
   int* order = binload + sched_ints(N, H, W);
   const int n_bins = N * ((H + 15) / 16) * ((W + 15) / 16);
-  P.bbox = bbox; P.rec = rec; P.fz = fz; P.order = order;
+  P.bbox = bbox; P.rec = rec; P.fz = fz; P.order = order; P.total_faces = NF;
   P.spill = reinterpret_cast<unsigned long long*>(order + sched_ints(N, H, W));
   if (hipMemsetAsync(binload, 0, (size_t)n_bins * 4, st) != hipSuccess) return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
   if (NF > 0) {
@@ -2019,7 +2026,7 @@ size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
   // LDS holds)
   const size_t nf = (size_t)(total_faces < 1 ? 1 : total_faces);
   return nf * 96 + ((nf + 3) / 4) * 16 + 2 * sched_ints(N < 0 ? 0 : N, H, W) * 4 +
-         raster_spill_bytes(N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
+         raster_spill_bytes(total_faces, N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
 }
 
 int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
