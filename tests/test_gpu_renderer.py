@@ -275,3 +275,58 @@ def test_kernel_timing_hook():
     assert all(0.0 < ms < 50.0 for v in got.values() for ms in v)
     with pytest.raises(RuntimeError):
         native.profile_end(8)  # not on any more
+
+
+def _soup(N, F, seed, behind=True):
+    """random triangle soup: sizes from sub-pixel to screen-filling, a few degenerate faces, a few crossing or behind
+    the camera plane; view-space coordinates (identity camera rotation, zero translation)"""
+    rs = np.random.RandomState(seed)
+    V = 3 * F
+    centre = np.concatenate([rs.uniform(-0.8, 0.8, (N, F, 1, 2)), rs.uniform(1.5, 4.0, (N, F, 1, 1))], -1)
+    size = np.exp(rs.uniform(np.log(0.005), np.log(1.5), (N, F, 1, 1)))
+    verts = (centre + size * rs.randn(N, F, 3, 3) * np.array([1, 1, 0.3])).astype(np.float32)
+    verts[:, 0, 1] = verts[:, 0, 0]                      # degenerate: two corners coincide
+    verts[:, 1, 2] = 0.5 * (verts[:, 1, 0] + verts[:, 1, 1])  # degenerate: collinear
+    if behind:
+        verts[:, 2, :, 2] = -1.0                          # fully behind the camera
+        verts[:, 3, 0, 2] = -0.5                          # crossing the camera plane
+    faces = np.arange(V).reshape(F, 3)
+    uvs = rs.rand(V, 2).astype(np.float32)
+    maps = rs.rand(N, 16, 16, 3).astype(np.float32)
+    R = np.tile(np.eye(3, dtype=np.float32), (N, 1, 1))
+    T = np.zeros((N, 3), np.float32)
+    return dict(verts=torch.tensor(verts.reshape(N, V, 3)), faces=torch.tensor(faces), verts_uvs=torch.tensor(uvs),
+                maps=torch.tensor(maps), R=torch.tensor(R), T=torch.tensor(T))
+
+
+@pytest.mark.parametrize("seed,F,K,img,sigma", [(0, 60, 8, 48, 1e-4), (1, 200, 50, 64, 1e-4), (2, 40, 3, (24, 40), 3e-3),
+                                                (3, 500, 20, 32, 1e-4)])
+def test_triangle_soup_matches_oracle(seed, F, K, img, sigma):
+    """nothing sphere-like: overlapping, degenerate, huge, tiny and behind-the-camera faces, per-mesh face tables"""
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesUV
+    N = 2
+    H, W = (img, img) if isinstance(img, int) else img
+    sc = _soup(N, F, seed)
+    dev = torch.device("cuda:0")
+    rend = Renderer(img, cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=sigma).to(dev)
+    verts = sc["verts"].to(dev).requires_grad_(True)
+    maps = sc["maps"].to(dev).requires_grad_(True)
+    R, T = sc["R"].to(dev).requires_grad_(True), sc["T"].to(dev).requires_grad_(True)
+    fb = sc["faces"].to(dev)[None].expand(N, -1, -1)
+    ub = sc["verts_uvs"].to(dev)[None].expand(N, -1, -1)
+    cot = np.random.RandomState(seed).randn(N, 4, H, W).astype(np.float32)
+    ref, (gv, gR, gT, gm) = _oracle(sc, H, W, K, S30, sigma, cot)
+    outs = []
+    for fused in (True, False):
+        rend.renderer.fused = fused
+        for t in (verts, maps, R, T):
+            t.grad = None
+        out = rend(Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub)), R, T)
+        out.backward(torch.tensor(cot, device=dev))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=0)
+        assert rel_err(verts.grad.cpu().numpy(), gv) < 2e-4
+        assert rel_err(maps.grad.cpu().numpy(), gm) < 1e-4
+        assert rel_err(R.grad.cpu().numpy(), gR) < 2e-4 and rel_err(T.grad.cpu().numpy(), gT) < 2e-4
+        outs.append(out.detach())
+    assert torch.equal(outs[0], outs[1])

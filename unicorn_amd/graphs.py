@@ -26,7 +26,9 @@ class GraphedStep:
         torch.cuda.synchronize()
         self._clear()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads of the process (e.g. the RCCL watchdog of a multi-GPU run) may call into HIP
+        # while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = fn()  # grads are created inside the capture: static tensors from the graph's pool
 
     def _clear(self):
