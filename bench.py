@@ -97,8 +97,12 @@ def main():
     a = ap.parse_args()
 
     rank, local, world = udist.env_world()
+    # rehearsal on a box with fewer GPUs than ranks: UNICORN_BENCH_BACKEND=gloo lets the ranks share a device
+    backend = os.environ.get("UNICORN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    udist.init("nccl")
+    udist.init(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
     native.lib()

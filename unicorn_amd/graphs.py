@@ -15,6 +15,11 @@ import torch
 class GraphedStep:
     def __init__(self, fn, grads_of=(), warmup=3):
         self.fn, self.leaves = fn, tuple(grads_of)
+        # the leaves' AccumulateGrad nodes were created on the default stream; running the backward on the capture
+        # stream is intended here
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
