@@ -128,9 +128,12 @@ def main():
         img.backward(cot)
         return img
 
-    # The step is launch bound in eager mode (~0.3 ms of Python / autograd per step against ~0.25 ms of kernels), so
+    # Eager steps cost 0.17-0.3 ms of Python / autograd on the host (box dependent) against ~0.165 ms of kernels, so
     # the timed loop replays the step's hipGraph: the same kernels on the same buffers, one launch per step.
-    launch, run = "eager", step
+    # (the eager rate is measured first: capturing afterwards leaves the leaves' AccumulateGrad nodes tied to the
+    # capture stream, which would slow later eager steps down with stream syncs)
+    eager_elapsed = udist.timed_steps(step, a.steps, a.warmup, world, cuda=True)
+    launch, elapsed = "eager", eager_elapsed
     if not a.eager:
         try:
             from unicorn_amd.graphs import GraphedStep
@@ -141,12 +144,10 @@ def main():
                 img.backward(cot)
                 return img
             run = GraphedStep(body, grads_of=(verts, maps, R, T))
+            elapsed = udist.timed_steps(run, a.steps, a.warmup, world, cuda=True)
             launch = "hipGraph replay of one captured Renderer forward + backward"
         except Exception as e:  # capture unsupported: fall back, and say so in the result
-            launch, run = f"eager (graph capture failed: {type(e).__name__}: {e})"[:200], step
-    elapsed = udist.timed_steps(run, a.steps, a.warmup, world, cuda=True)
-    eager_elapsed = elapsed if run is step else udist.timed_steps(step, a.steps, a.warmup, world, cuda=True)
-
+            launch = f"eager (graph capture failed: {type(e).__name__}: {e})"[:200]
     # roofline leg (rank 0 only): the same steps again, eagerly, with (i) HIP events recorded by the library on the
     # launch stream right around the two dominant kernels (ur_profile_begin/end) and (ii) events around every C-ABI call
     result = None

@@ -1,7 +1,6 @@
-"""dev helper: host-side enqueue time per step vs GPU time per step for the bench workload."""
-import os, sys, time, math
+import os, sys, time, cProfile, pstats
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, "/root/repo")
 from unicorn_amd import native, synth
 from unicorn_amd.renderer import Renderer
 from unicorn_amd.structures import Meshes, TexturesUV
@@ -18,25 +17,14 @@ def step():
     meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
     img = rend(meshes, R, T)
     img.backward(cot)
-for _ in range(20): step()
+for _ in range(30): step()
 torch.cuda.synchronize()
-n = 200
+n = 300
 t0 = time.perf_counter()
 for _ in range(n): step()
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print("host enqueue per step: %.1f us ; wall per step incl. drain: %.1f us" % ((t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
-# forward only / pieces
-def fwd_only():
-    meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
-    return rend(meshes, R, T)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(n): img = fwd_only()
-t1 = time.perf_counter(); torch.cuda.synchronize()
-print("forward host enqueue per step: %.1f us" % ((t1 - t0) / n * 1e6))
-import cProfile, pstats
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print("host enqueue per step: %.1f us ; wall: %.1f us" % ((t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
 pr = cProfile.Profile(); pr.enable()
-for _ in range(100): step()
+for _ in range(300): step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
