@@ -73,6 +73,23 @@ int check_launch(const char* what) {
   return UR_OK;
 }
 
+// Kernels that want more than 64 KB of dynamic LDS must be told so once per (kernel, device).  `slot` is a small
+// table per call site: the largest size configured so far on each device (process-wide, relaxed atomics: a race only
+// repeats the idempotent call).
+constexpr int kMaxDevices = 64;
+struct LdsSlot { std::atomic<size_t> done[kMaxDevices]; };
+
+int ensure_dynamic_lds(const void* kernel, size_t bytes, LdsSlot& slot) {
+  if (bytes <= 64 * 1024) return UR_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+  if (dev >= 0 && slot.done[dev].load(std::memory_order_relaxed) >= bytes) return UR_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+  if (dev >= 0) slot.done[dev].store(bytes, std::memory_order_relaxed);
+  return UR_OK;
+}
+
 // Wave-wide inclusive scans on the VALU's data-parallel-primitive lanes (row shifts inside a 16-lane row, then the
 // two row broadcasts): six VALU operations, where a __shfl_up ladder is six dependent trips through the LDS crossbar.
 // `ident` is the operation's neutral element (what a lane combines with when it has no source lane).
@@ -947,13 +964,8 @@ template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
   P.nby = (P.H + 15) / 16;
   P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K);
   const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
-  static thread_local size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_raster<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-    configured = lds;
-  }
+  static LdsSlot lds_slot;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE>), lds, lds_slot)) return rc;
   const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
   {
@@ -2053,13 +2065,8 @@ int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t 
   const int vwin = (V + nwin - 1) / nwin;
   const size_t lds = (size_t)vwin * 3 * 8 + 16 * 12 * 4;
   if (N > 65535 || nwin > 65535) return fail(UR_ERR_INVALID_ARG, "too many meshes / vertices per call");
-  static thread_local size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_project_faces_bwd_mesh),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = lds;
-  }
+  static LdsSlot lds_slot;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_project_faces_bwd_mesh), lds, lds_slot)) return rc;
   if (nwin > 1) {
     if (grad_R) (void)hipMemsetAsync(grad_R, 0, (size_t)N * 36, (hipStream_t)stream);
     if (grad_T) (void)hipMemsetAsync(grad_T, 0, (size_t)N * 12, (hipStream_t)stream);
@@ -2156,7 +2163,9 @@ int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face,
   const int64_t npix = (int64_t)N * H * W;
   if (npix == 0) return UR_OK;
   const size_t lds = (size_t)K * 64 * 4;
-  if (lds > 64 * 1024) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d too large for the blend backward", K);
+  if (lds > 150 * 1024) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d too large for the blend backward", K);
+  static LdsSlot lds_slot;
+  if (int rc2 = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_shade_bwd), lds, lds_slot)) return rc2;
   hipLaunchKernelGGL(k_shade_bwd, dim3((unsigned)((npix + 63) / 64)), dim3(64), lds, (hipStream_t)stream, P);
   return check_launch("k_shade_bwd");
 }
@@ -2172,13 +2181,8 @@ int ur_mesh_regularizers(const float* verts, int N, int V, const int32_t* edge_q
   const size_t lds_full = 128 + (size_t)V * 3 * 8;
   const int lds_acc = lds_full <= 150 * 1024;
   const size_t lds = lds_acc ? lds_full : 128;
-  static thread_local size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mesh_reg),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = lds;
-  }
+  static LdsSlot lds_slot;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_mesh_reg), lds, lds_slot)) return rc;
   hipLaunchKernelGGL(k_mesh_reg, dim3((unsigned)N), dim3(1024), lds, (hipStream_t)stream, verts, V,
                      reinterpret_cast<const int4*>(edge_quads), E, nbr_offsets, nbr_index, normal_sum, laplacian_sum,
                      grad_normal, grad_laplacian, scratch, lds_acc);
