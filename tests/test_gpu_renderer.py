@@ -330,3 +330,19 @@ def test_triangle_soup_matches_oracle(seed, F, K, img, sigma):
         assert rel_err(R.grad.cpu().numpy(), gR) < 2e-4 and rel_err(T.grad.cpu().numpy(), gT) < 2e-4
         outs.append(out.detach())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_debug_returns_blend_intermediates():
+    """debug=True (renderer.py:199-200): (colors + background layer, alpha + trailing 1, occ_alpha, image)"""
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, 32, 6, seed=8, debug=True)
+    sc2, plain, meshes2, leaves2 = _setup(2, 2, 32, 6, seed=8)
+    colors, alpha, occ, image = rend(meshes, R, T)
+    assert colors.shape == (2, 32, 32, 7, 3) and alpha.shape == occ.shape == (2, 32, 32, 7)
+    assert torch.equal(image, plain(meshes2, leaves2[2], leaves2[3]))
+    # the reference's own composition of the intermediates (renderer.py:196-197) gives the image back
+    rgb = (occ[..., None] * alpha[..., None] * colors).sum(-2).permute(0, 3, 1, 2).detach()
+    assert float((rgb - image.detach()[:, :3]).abs().max()) <= 1e-5
+    assert float(((1 - occ.detach()[..., -1]) - image.detach()[:, 3]).abs().max()) <= 1e-6
+    assert torch.all(colors[..., -1, :] == 1) and torch.all(alpha[..., -1] == 1) and torch.all(occ[..., 0] == 1)
+    image.sum().backward()
+    assert verts.grad is not None and maps.grad is not None

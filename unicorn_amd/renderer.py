@@ -148,8 +148,6 @@ class LayeredShader(nn.Module):
             raise NotImplementedError
         if self.materials is None:
             self.materials = lighting.Materials()
-        if debug:
-            raise NotImplementedError("debug=True returns the blend's intermediates; not built")
 
     def to(self, device):
         if self.cameras is not None:
@@ -174,21 +172,46 @@ class LayeredShader(nn.Module):
                                   _rgb3(bp.background_color), None if ambient == (1.0, 1.0, 1.0) else ambient,
                                   self.blend_mode(bp))
 
+    def debug_outputs(self, colors, fragments, bp, image):
+        """debug=True (renderer.py:199-200): the blend's intermediates next to the image -- colours with the
+        background appended as layer K, alpha with a trailing 1, and the transmittance in front of every layer.
+        Inspection only: a few elementwise torch ops over the fragments; the image itself comes from the kernel."""
+        N, H, W, K = fragments.dists.shape
+        mask = fragments.pix_to_face_i32 >= 0
+        if bp.sigma == 0:
+            alpha = (fragments.dists <= 0).float() * mask
+        elif self.clip_inside:
+            alpha = torch.exp(-fragments.dists.clamp(0) / bp.sigma) * mask
+        else:
+            alpha = torch.sigmoid(-fragments.dists / bp.sigma) * mask
+        one = torch.ones(N, H, W, 1, device=alpha.device)
+        occ_alpha = torch.cat([one, torch.cumprod(1.0 - alpha, dim=-1)], dim=-1)
+        bg = torch.tensor(_rgb3(bp.background_color), dtype=torch.float32, device=alpha.device)
+        colors = torch.cat([colors, bg[None, None, None, None].expand(N, H, W, 1, -1)], dim=-2)
+        return colors, torch.cat([alpha, one], dim=-1), occ_alpha, image
+
     def forward(self, fragments, meshes, **kwargs):
         bp = kwargs.get("blend_params", self.blend_params)
         tex = meshes.textures
+        colors = None
         if self.shading_type != 'raw' or not isinstance(tex, TexturesUV):
             # lit colours (renderer.py:165-171) or vertex colours, then layered_rgb_blend over them (ur_blend_colors)
             colors = lit_colors(self.shading_type, meshes, fragments, kwargs.get("lights", self.lights),
                                 kwargs.get("materials", self.materials), kwargs["R"], kwargs["T"])
-            return ops.blend_colors(colors, fragments.pix_to_face_i32, fragments.dists, None, self.blend_mode(bp),
-                                    bp.sigma, bp.gamma, _rgb3(bp.background_color))
-        ambient = _rgb3(self.lights.ambient_color)
-        face_uvs, shared = tex.faces_verts_uvs()
-        return ops.shade_blend(fragments.pix_to_face_i32, fragments.bary_coords, fragments.dists,
-                               tex.maps_padded().float(), face_uvs.float(), shared, fragments.mesh_first_face,
-                               bp.sigma, _rgb3(bp.background_color), None if ambient == (1.0, 1.0, 1.0) else ambient,
-                               self.blend_mode(bp))
+            image = ops.blend_colors(colors, fragments.pix_to_face_i32, fragments.dists, None, self.blend_mode(bp),
+                                     bp.sigma, bp.gamma, _rgb3(bp.background_color))
+        else:
+            ambient = _rgb3(self.lights.ambient_color)
+            face_uvs, shared = tex.faces_verts_uvs()
+            image = ops.shade_blend(fragments.pix_to_face_i32, fragments.bary_coords, fragments.dists,
+                                    tex.maps_padded().float(), face_uvs.float(), shared, fragments.mesh_first_face,
+                                    bp.sigma, _rgb3(bp.background_color),
+                                    None if ambient == (1.0, 1.0, 1.0) else ambient, self.blend_mode(bp))
+        if not self.debug:
+            return image
+        if colors is None:
+            colors = lit_colors('raw', meshes, fragments, kwargs.get("lights", self.lights), None, None, None)
+        return self.debug_outputs(colors, fragments, bp, image)
 
 
 def lit_colors(shading_type, meshes, fragments, lights, materials, R, T):
@@ -248,7 +271,7 @@ class MeshRenderer(nn.Module):
 
     def forward(self, meshes, **kwargs):
         if self.fused and isinstance(self.shader, LayeredShader) and self.shader.shading_type == 'raw' \
-                and isinstance(meshes.textures, TexturesUV):
+                and isinstance(meshes.textures, TexturesUV) and not self.shader.debug:
             return self.shader.render_fused(self.rasterizer, meshes, **kwargs)
         fragments = self.rasterizer(meshes, **kwargs)
         return self.shader(fragments, meshes, **kwargs)
