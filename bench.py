@@ -161,7 +161,7 @@ def main():
         per_call = native.timing_summary()
         native.enable_timing(False)
         dom = max(kernel_ms, key=kernel_ms.get)  # the dominant kernel: k_raster<2> (fused forward)
-        dom_call = {"k_raster<2>": "ur_render_layered_forward", "k_render_bwd": "ur_render_layered_backward"}[dom]
+        dom_call = {"k_raster<2>": "ur_render_meshes_forward", "k_render_bwd": "ur_render_meshes_backward"}[dom]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):  # PMC counters cannot be read from inside the process: last committed measurement

@@ -207,6 +207,43 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
                                const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
                                float* grad_face_verts, float* grad_maps, void* stream);
 
+/*
+ * The whole render step of a batch of EQUAL-SIZED meshes (the reference's case: one template topology, unicorn.py:86-93)
+ * in one call each way: camera + face gather + rasterizer + shader.
+ * Replaces: MeshRenderer.forward (renderer.py:48-49: MeshRasterizer.transform + rasterize_meshes + LayeredShader) as
+ *           called by Renderer.forward (renderer.py:80-81), and its autograd (trainer.py:151).
+ * Same numbers as ur_project_faces + ur_render_layered_forward (bit for bit) and their backwards.  Up to 8192 faces
+ * per mesh everything before the rasterizer is ONE launch (one workgroup per mesh: projection, face records, per-bin
+ * load in LDS, per-mesh schedule interleaved across meshes -- no global atomics, nothing to pre-zero); larger meshes
+ * go through the per-face kernels inside the same call.
+ *   verts (N,V,3), faces / faces_mesh_stride as in ur_project_faces, mesh_first_face[n] = n*F, mesh_num_faces[n] = F ;
+ *   face_verts (N*F,3,3): OUTPUT (the projected corners; the caller may want them, the backward does not) ;
+ *   zero_grad_face_verts (N*F,3,3) / zero_grad_maps (N,Ht,Wt,3): optional buffers the forward clears on the way, to be
+ *   handed to ur_render_meshes_backward with grads_are_zero = 1 (saves the backward a fill launch); NULL = skip.
+ * Backward: grad_image (N,4,H,W) -> grad_maps (N,Ht,Wt,3), grad_verts (N,V,3), grad_R (N,3,3), grad_T (N,3); any may
+ *   be NULL.  grad_face_verts (N*F,3,3) is the intermediate accumulator (needed when any of grad_verts / grad_R /
+ *   grad_T is wanted).  grads_are_zero = 0 makes the call clear grad_face_verts and grad_maps itself.
+ *   layers / workspace: what the forward left; scratch: ur_backward_scratch_bytes() of uninitialised memory.
+ */
+int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                             const float* T, float sx, float sy, int N, int V, int F, const int64_t* mesh_first_face,
+                             const int64_t* mesh_num_faces, int H, int W, float blur_radius, int K,
+                             int clip_barycentric_coords, int cull_backfaces, const float* maps, const float* face_uvs,
+                             int face_uvs_shared, int Ht, int Wt, float sigma, const float* background,
+                             const float* ambient, int mode, float* face_verts, float* image, int32_t* layers,
+                             float* zero_grad_face_verts, float* zero_grad_maps, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+int ur_render_meshes_backward(const float* grad_image, const float* verts, const int64_t* faces,
+                              int64_t faces_mesh_stride, const float* R, const float* T, float sx, float sy, int N,
+                              int V, int F, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int H, int W,
+                              float blur_radius, int K, int clip_barycentric_coords, const float* maps,
+                              const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                              const float* background, const float* ambient, int mode, const int32_t* layers,
+                              const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                              float* grad_face_verts, float* grad_maps, int grads_are_zero, float* grad_verts,
+                              float* grad_R, float* grad_T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

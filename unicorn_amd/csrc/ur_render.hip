@@ -133,6 +133,40 @@ constexpr int kPrepBins = 4096;  // bins per image the face-prep kernel counts i
 // ------------------------------------------------------------------------------------------------------------------
 // face records
 // ------------------------------------------------------------------------------------------------------------------
+// One face: blur-expanded box, record, nearest depth (layout in ur_device.h).  Returns true when the face is culled.
+__device__ __forceinline__ bool face_record(const float c[9], float r, int cull, float4& bb, float4 rc[5]) {
+  const float v0x = c[0], v0y = c[1], z0 = c[2], v1x = c[3], v1y = c[4], z1 = c[5], v2x = c[6], v2y = c[7], z2 = c[8];
+  const float zmax = max_s(max_s(z0, z1), z2);
+  const float face_area = (v0x - v1x) * (v2y - v1y) - (v0y - v1y) * (v2x - v1x);  // edge(v0; v1, v2)
+  const bool culled = (zmax < kEps) || (face_area <= kEps && face_area >= -kEps) || (cull && face_area < 0.0f);
+  float xlo = min_s(min_s(v0x, v1x), v2x) - r, xhi = max_s(max_s(v0x, v1x), v2x) + r;
+  const float ylo = min_s(min_s(v0y, v1y), v2y) - r, yhi = max_s(max_s(v0y, v1y), v2y) + r;
+  if (culled) { xlo = __builtin_inff(); xhi = -__builtin_inff(); }
+  bb = make_float4(xlo, xhi, ylo, yhi);
+  const float denom = ((v2x - v0x) * (v1y - v0y) - (v2y - v0y) * (v1x - v0x)) + kEps;  // edge(v2; v0, v1) + eps
+  const float d01x = v1x - v0x, d01y = v1y - v0y, d12x = v2x - v1x, d12y = v2y - v1y;
+  const float d02x = v2x - v0x, d02y = v2y - v0y;
+  const float l01 = d01x * d01x + d01y * d01y, l02 = d02x * d02x + d02y * d02y, l12 = d12x * d12x + d12y * d12y;
+  rc[0] = make_float4(v0x, v0y, v1x, v1y);
+  rc[1] = make_float4(v2x, v2y, z0, z1);
+  rc[2] = make_float4(z2, denom, 1.0f / denom, l01);
+  rc[3] = make_float4(l02, l12, 1.0f / l01, 1.0f / l02);
+  rc[4] = make_float4(1.0f / l12, d12x, d12y, min_s(min_s(z0, z1), z2));
+  return culled;
+}
+
+// pixel rectangle (columns c0..c1, rows r0..r1, a pixel of slack either way) a blur-expanded box may touch: the load
+// estimate of the workgroup schedule counts +1 on every 16x16 bin it overlaps -- this only orders work, it decides
+// nothing
+__device__ __forceinline__ void box_pixels(const float4 bb, int H, int W, int& c0, int& c1, int& r0, int& r1) {
+  const float rx = (W > H) ? 2.0f * (float)W / (float)H : 2.0f, ry = (H > W) ? 2.0f * (float)H / (float)W : 2.0f;
+  // column c has x = rx/2 - rx (c + 0.5) / W  (+X left), row likewise
+  c0 = max(0, (int)floorf((0.5f * rx - bb.y) * (float)W / rx - 0.5f) - 1);
+  c1 = min(W - 1, (int)ceilf((0.5f * rx - bb.x) * (float)W / rx - 0.5f) + 1);
+  r0 = max(0, (int)floorf((0.5f * ry - bb.w) * (float)H / ry - 0.5f) - 1);
+  r1 = min(H - 1, (int)ceilf((0.5f * ry - bb.z) * (float)H / ry - 0.5f) + 1);
+}
+
 __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv, int64_t NF, float r, int cull,
                                                    float4* __restrict__ bbox, float4* __restrict__ rec,
                                                    float* __restrict__ fz, const int64_t* __restrict__ first, int N,
@@ -140,27 +174,16 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < NF;
   bool culled = true;
-  float xlo = 0.0f, xhi = 0.0f, ylo = 0.0f, yhi = 0.0f;
+  float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (live) {
-  const float* p = fv + i * 9;
-  const float v0x = p[0], v0y = p[1], z0 = p[2], v1x = p[3], v1y = p[4], z1 = p[5], v2x = p[6], v2y = p[7], z2 = p[8];
-  const float zmax = max_s(max_s(z0, z1), z2);
-  const float face_area = (v0x - v1x) * (v2y - v1y) - (v0y - v1y) * (v2x - v1x);  // edge(v0; v1, v2)
-  culled = (zmax < kEps) || (face_area <= kEps && face_area >= -kEps) || (cull && face_area < 0.0f);
-  xlo = min_s(min_s(v0x, v1x), v2x) - r; xhi = max_s(max_s(v0x, v1x), v2x) + r;
-  ylo = min_s(min_s(v0y, v1y), v2y) - r; yhi = max_s(max_s(v0y, v1y), v2y) + r;
-  if (culled) { xlo = __builtin_inff(); xhi = -__builtin_inff(); }
-  bbox[i] = make_float4(xlo, xhi, ylo, yhi);
-  fz[i] = min_s(min_s(z0, z1), z2);
-  const float denom = ((v2x - v0x) * (v1y - v0y) - (v2y - v0y) * (v1x - v0x)) + kEps;  // edge(v2; v0, v1) + eps
-  const float d01x = v1x - v0x, d01y = v1y - v0y, d12x = v2x - v1x, d12y = v2y - v1y;
-  const float d02x = v2x - v0x, d02y = v2y - v0y;
-  const float l01 = d01x * d01x + d01y * d01y, l02 = d02x * d02x + d02y * d02y, l12 = d12x * d12x + d12y * d12y;
-  rec[5 * i + 0] = make_float4(v0x, v0y, v1x, v1y);
-  rec[5 * i + 1] = make_float4(v2x, v2y, z0, z1);
-  rec[5 * i + 2] = make_float4(z2, denom, 1.0f / denom, l01);
-  rec[5 * i + 3] = make_float4(l02, l12, 1.0f / l01, 1.0f / l02);
-  rec[5 * i + 4] = make_float4(1.0f / l12, d12x, d12y, min_s(min_s(z0, z1), z2));
+    const float* p = fv + i * 9;
+    const float c[9] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
+    float4 rc[5];
+    culled = face_record(c, r, cull, bb, rc);
+    bbox[i] = bb;
+    fz[i] = rc[4].w;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) rec[5 * i + q] = rc[q];
   }
   // ---- load estimate for the workgroup schedule: +1 on every 16x16 bin the expanded box overlaps (a pixel of slack
   //      either way -- this only orders the work, it decides nothing).  The workgroup first counts in LDS for the
@@ -189,12 +212,8 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
       const int mid = (lo + hi + 1) >> 1;
       if (first[mid] <= i) lo = mid; else hi = mid - 1;
     }
-    const float rx = (W > H) ? 2.0f * (float)W / (float)H : 2.0f, ry = (H > W) ? 2.0f * (float)H / (float)W : 2.0f;
-    // column c has x = rx/2 - rx (c + 0.5) / W  (+X left), row likewise
-    const int c0 = max(0, (int)floorf((0.5f * rx - xhi) * (float)W / rx - 0.5f) - 1);
-    const int c1 = min(W - 1, (int)ceilf((0.5f * rx - xlo) * (float)W / rx - 0.5f) + 1);
-    const int r0 = max(0, (int)floorf((0.5f * ry - yhi) * (float)H / ry - 0.5f) - 1);
-    const int r1 = min(H - 1, (int)ceilf((0.5f * ry - ylo) * (float)H / ry - 0.5f) + 1);
+    int c0, c1, r0, r1;
+    box_pixels(bb, H, W, c0, c1, r0, r1);
     const bool local = use_lds && lo == s_mesh;
     for (int by = r0 >> 4; by <= (r1 >> 4); ++by)
       for (int bx = c0 >> 4; bx <= (c1 >> 4); ++bx) {
@@ -214,7 +233,8 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
 // Workgroup schedule: bins sorted by descending load estimate (counting sort over 256 load classes, one workgroup).
 // The long-running bins -- silhouettes, where many faces pile up -- then start first and the cheap ones fill the gaps
 // at the end, instead of a late heavy bin stretching the kernel.  Any permutation gives the same results.
-__global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binload, int n_bins, int* __restrict__ order) {
+__global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binload, int n_bins, int* __restrict__ order,
+                                                    int parts, int bins_per_mesh) {
   __shared__ int s_hist[256];
   __shared__ int s_wsum[4];
   __shared__ int s_max;
@@ -222,14 +242,29 @@ __global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binl
   if (tid < 256) s_hist[tid] = 0;
   if (tid == 0) s_max = 1;
   // the first four loads of every thread stay in registers for the three passes (covers 4096 bins)
+  // load of bin i: binload[i], or -- when the per-mesh prep kernel left `parts` partial counts per mesh, laid out
+  // [mesh][part][bin] -- their sum
+  auto load_of = [&](int i) {
+    if (parts == 1) return binload[i];
+    const int m = i / bins_per_mesh, b = i - m * bins_per_mesh;
+    const int* p = binload + ((int64_t)m * parts) * bins_per_mesh + b;
+    int sum = 0;
+    for (int q0 = 0; q0 < parts; q0 += 8) {  // eight independent loads in flight
+      int t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = (q0 + u < parts) ? p[(int64_t)(q0 + u) * bins_per_mesh] : 0;
+      sum += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    return sum;
+  };
   int v[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = (tid + q * 1024 < n_bins) ? binload[tid + q * 1024] : 0;
+  for (int q = 0; q < 4; ++q) v[q] = (tid + q * 1024 < n_bins) ? load_of(tid + q * 1024) : 0;
   auto each = [&](auto fn) {  // fn(load, bin index) over this thread's bins
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (tid + q * 1024 < n_bins) fn(v[q], tid + q * 1024);
-    for (int i = tid + 4096; i < n_bins; i += 1024) fn(binload[i], i);
+    for (int i = tid + 4096; i < n_bins; i += 1024) fn(load_of(i), i);
   };
   __syncthreads();
   int mx = 1;
@@ -256,6 +291,83 @@ __global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binl
   }
   __syncthreads();
   each([&](int x, int i) { order[atomicAdd(&s_hist[cls(x, i)], 1)] = i; });
+}
+
+// camera: view = X R + T, x_ndc = sx x / z, y_ndc = sy y / z, depth = view z (operation order fixed: part of the parity contract)
+__device__ __forceinline__ void project_vertex(const float* __restrict__ p, const float* __restrict__ r,
+                                               const float* __restrict__ t, float sx, float sy, float out[3]) {
+  const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
+  const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
+  const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
+  out[0] = (sx * vx) / vz;
+  out[1] = (sy * vy) / vz;
+  out[2] = vz;
+}
+
+constexpr int kMeshPrepMaxFaces = 8192;  // up to here the per-mesh prep kernel (<= 32 workgroups per mesh)
+
+// workgroups per mesh of k_project_prep_mesh = partial load counts per (mesh, bin); 1 when that kernel is not used
+__host__ __device__ inline int prep_parts(int64_t total_faces, int N) {
+  const int64_t F = N > 0 ? (total_faces + N - 1) / N : 0;
+  return (F > 0 && F <= kMeshPrepMaxFaces) ? (int)((F + 255) / 256) : 1;
+}
+
+// Equal-sized meshes (the reference's case: one template topology), ONE launch for everything that comes before the
+// schedule: camera projection + face gather (= k_project_faces), face records (= k_face_prep, same arithmetic, same
+// bits) and the per-bin load count.  Workgroup (part, mesh) takes 256 consecutive faces of its mesh, counts in LDS and
+// STORES its partial counts ([mesh][part][bin]; k_bin_order adds the parts up): no global atomics, nothing to zero
+// beforehand.  (A per-mesh sort interleaved rank by rank, which would also save the k_bin_order launch, was tried: it
+// costs the two big kernels 5 us each -- strict heaviest-first matters.)  Optionally the workgroups also clear their
+// share of the two gradient accumulators the backward will add into (saves the backward a fill launch).
+__global__ void __launch_bounds__(256) k_project_prep_mesh(
+    const float* __restrict__ verts, const int64_t* __restrict__ faces, int64_t fstride, const float* __restrict__ R,
+    const float* __restrict__ T, float sx, float sy, int N, int V, int F, float r, int cull, int H, int W,
+    float* __restrict__ face_verts, float4* __restrict__ bbox, float4* __restrict__ rec, float* __restrict__ fz,
+    int* __restrict__ binload, float* __restrict__ zero_a, int zero_a_n, float* __restrict__ zero_b, int zero_b_n) {
+  __shared__ int s_load[kPrepBins];
+  const int part = blockIdx.x, parts = gridDim.x, n = blockIdx.y, tid = threadIdx.x;
+  const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nbins = nbx * nby;
+  for (int j = tid; j < nbins; j += 256) s_load[j] = 0;
+  if (zero_a) {
+    float* z = zero_a + (int64_t)n * zero_a_n;
+    for (int j = part * 256 + tid; j < zero_a_n; j += parts * 256) z[j] = 0.0f;
+  }
+  if (zero_b) {
+    float* z = zero_b + (int64_t)n * zero_b_n;
+    for (int j = part * 256 + tid; j < zero_b_n; j += parts * 256) z[j] = 0.0f;
+  }
+  __syncthreads();
+  const int f = part * 256 + tid;
+  if (f < F) {
+    const float* rm = R + (int64_t)n * 9;
+    const float* tv = T + (int64_t)n * 3;
+    const int64_t* fc = faces + (int64_t)n * fstride + (int64_t)f * 3;
+    const float* vp = verts + (int64_t)n * V * 3;
+    float c[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int64_t vi = min(max(fc[k], (int64_t)0), (int64_t)V - 1);
+      project_vertex(vp + vi * 3, rm, tv, sx, sy, c + 3 * k);
+    }
+    const int64_t i = (int64_t)n * F + f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) face_verts[i * 9 + q] = c[q];
+    float4 bb, rc[5];
+    const bool culled = face_record(c, r, cull, bb, rc);
+    bbox[i] = bb;
+    fz[i] = rc[4].w;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) rec[5 * i + q] = rc[q];
+    if (!culled) {
+      int c0, c1, r0, r1;
+      box_pixels(bb, H, W, c0, c1, r0, r1);
+      for (int by = r0 >> 4; by <= (r1 >> 4); ++by)
+        for (int bx = c0 >> 4; bx <= (c1 >> 4); ++bx) atomicAdd(&s_load[by * nbx + bx], 1);
+    }
+  }
+  __syncthreads();
+  int* out = binload + ((int64_t)n * parts + part) * nbins;
+  for (int j = tid; j < nbins; j += 256) out[j] = s_load[j];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -976,12 +1088,23 @@ template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
 }
 
 // workspace = [bbox: NF float4][records: NF x 5 float4][nearest depth: NF float, padded to 16 B]
-//             [bin loads: N * bins int, padded to 16 B][schedule: N * bins int, padded][K-list spill]
+//             [schedule: N * bins int, padded to 16 B][bin loads: N * bins int, padded, x prep_parts][K-list spill]
 size_t sched_ints(int N, int H, int W) { return (((size_t)N * ((H + 15) / 16) * ((W + 15) / 16)) + 3) / 4 * 4; }
 
 const int* sched_order(const void* ws, int64_t NF, int N, int H, int W) {
   const float* fz = reinterpret_cast<const float*>(reinterpret_cast<const float4*>(ws) + 6 * NF);
-  return reinterpret_cast<const int*>(fz + ((NF + 3) / 4) * 4) + sched_ints(N, H, W);
+  return reinterpret_cast<const int*>(fz + ((NF + 3) / 4) * 4);
+}
+
+// lays the workspace out and points P at its parts
+void carve_workspace(void* ws, int64_t NF, int N, int H, int W, RasterParams& P, int*& binload, int*& order) {
+  float4* bbox = reinterpret_cast<float4*>(ws);
+  float4* rec = bbox + NF;
+  float* fz = reinterpret_cast<float*>(rec + 5 * NF);
+  order = reinterpret_cast<int*>(fz + ((NF + 3) / 4) * 4);
+  binload = order + sched_ints(N, H, W);
+  P.bbox = bbox; P.rec = rec; P.fz = fz; P.order = order; P.total_faces = NF;
+  P.spill = reinterpret_cast<unsigned long long*>(binload + sched_ints(N, H, W) * prep_parts(NF, N));
 }
 
 int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const int64_t* first, int N, int H, int W,
@@ -989,14 +1112,13 @@ int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const 
   const size_t need = ur_workspace_bytes(NF, N, H, W, K);
   if (ws_bytes < need) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
-  float4* bbox = reinterpret_cast<float4*>(ws);
-  float4* rec = bbox + NF;
-  float* fz = reinterpret_cast<float*>(rec + 5 * NF);
-  int* binload = reinterpret_cast<int*>(fz + ((NF + 3) / 4) * 4);
-  int* order = binload + sched_ints(N, H, W);
+  int* binload = nullptr;
+  int* order = nullptr;
+  carve_workspace(ws, NF, N, H, W, P, binload, order);
+  float4* bbox = const_cast<float4*>(P.bbox);
+  float4* rec = const_cast<float4*>(P.rec);
+  float* fz = const_cast<float*>(P.fz);
   const int n_bins = N * ((H + 15) / 16) * ((W + 15) / 16);
-  P.bbox = bbox; P.rec = rec; P.fz = fz; P.order = order; P.total_faces = NF;
-  P.spill = reinterpret_cast<unsigned long long*>(order + sched_ints(N, H, W));
   if (hipMemsetAsync(binload, 0, (size_t)n_bins * 4, st) != hipSuccess) return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
   if (NF > 0) {
     hipLaunchKernelGGL(k_face_prep, dim3((unsigned)((NF + 255) / 256)), dim3(256), 0, st, face_verts, NF,
@@ -1004,7 +1126,7 @@ int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const 
     int rc = check_launch("k_face_prep");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_bin_order, dim3(1), dim3(1024), 0, st, binload, n_bins, order);
+  hipLaunchKernelGGL(k_bin_order, dim3(1), dim3(1024), 0, st, binload, n_bins, order, 1, n_bins);
   return check_launch("k_bin_order");
 }
 
@@ -1556,16 +1678,12 @@ __global__ void __launch_bounds__(256) k_project_faces(const float* __restrict__
   if (i >= (int64_t)N * F * 3) return;
   const int n = (int)(i / ((int64_t)F * 3));
   const int fc = (int)(i - (int64_t)n * F * 3);
-  const int64_t vi = faces[(int64_t)n * fstride + fc];
-  const float* p = verts + ((int64_t)n * V + vi) * 3;
-  const float* r = R + (int64_t)n * 9;
-  const float* t = T + (int64_t)n * 3;
-  const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
-  const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
-  const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
-  out[i * 3 + 0] = (sx * vx) / vz;
-  out[i * 3 + 1] = (sy * vy) / vz;
-  out[i * 3 + 2] = vz;
+  const int64_t vi = min(max(faces[(int64_t)n * fstride + fc], (int64_t)0), (int64_t)V - 1);  // no wild reads
+  float o[3];
+  project_vertex(verts + ((int64_t)n * V + vi) * 3, R + (int64_t)n * 9, T + (int64_t)n * 3, sx, sy, o);
+  out[i * 3 + 0] = o[0];
+  out[i * 3 + 1] = o[1];
+  out[i * 3 + 2] = o[2];
 }
 
 // One workgroup per mesh: per-corner gradients are first summed per VERTEX in LDS (the projection is linear in the
@@ -2037,7 +2155,8 @@ size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
   // bbox (16 B) + record (80 B) + nearest depth (4 B) per face, the workgroup schedule, then the spill area of the per-pixel K-lists (only when K exceeds what
   // LDS holds)
   const size_t nf = (size_t)(total_faces < 1 ? 1 : total_faces);
-  return nf * 96 + ((nf + 3) / 4) * 16 + 2 * sched_ints(N < 0 ? 0 : N, H, W) * 4 +
+  return nf * 96 + ((nf + 3) / 4) * 16 +
+         (size_t)(1 + prep_parts(total_faces, N)) * sched_ints(N < 0 ? 0 : N, H, W) * 4 +
          raster_spill_bytes(total_faces, N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
 }
 
@@ -2302,6 +2421,92 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
     hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
   }
   return check_launch("k_render_bwd");
+}
+
+
+// ---- whole render step over equal-sized meshes: camera + rasterizer + shader in one call each way ------------------
+int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                             const float* T, float sx, float sy, int N, int V, int F, const int64_t* mesh_first_face,
+                             const int64_t* mesh_num_faces, int H, int W, float blur_radius, int K,
+                             int clip_barycentric_coords, int cull_backfaces, const float* maps, const float* face_uvs,
+                             int face_uvs_shared, int Ht, int Wt, float sigma, const float* background,
+                             const float* ambient, int mode, float* face_verts, float* image, int32_t* layers,
+                             float* zero_grad_face_verts, float* zero_grad_maps, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!verts || !faces || !R || !T || !face_verts || !image || !layers) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  const int64_t NF = (int64_t)(N < 0 ? 0 : N) * F;
+  if (NF > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "more than 2^31-1 faces");
+  RasterParams P{};
+  int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
+                              face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (N == 0) return UR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nbins = ((H + 15) / 16) * ((W + 15) / 16);
+  const int64_t n_gfv = (int64_t)F * 9, n_gmap = (int64_t)Ht * Wt * 3;
+  if (F > 0 && F <= kMeshPrepMaxFaces && nbins <= kPrepBins && n_gfv <= 0x7fffffffLL && n_gmap <= 0x7fffffffLL &&
+      N <= 0x7fffffff / nbins && N <= 65535) {
+    const size_t need = ur_workspace_bytes(NF, N, H, W, K);
+    if (workspace_bytes < need) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+    int* binload = nullptr;
+    int* order = nullptr;
+    carve_workspace(workspace, NF, N, H, W, P, binload, order);
+    const int parts = prep_parts(NF, N);
+    hipLaunchKernelGGL(k_project_prep_mesh, dim3((unsigned)parts, (unsigned)N), dim3(256), 0, st, verts, faces, faces_mesh_stride, R, T,
+                       sx, sy, N, V, F, sqrtf(blur_radius), cull_backfaces, H, W, face_verts, const_cast<float4*>(P.bbox),
+                       const_cast<float4*>(P.rec), const_cast<float*>(P.fz), binload, zero_grad_face_verts, (int)n_gfv,
+                       zero_grad_maps, (int)n_gmap);
+    rc = check_launch("k_project_prep_mesh");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bin_order, dim3(1), dim3(1024), 0, st, binload, N * nbins, order, parts, nbins);
+    rc = check_launch("k_bin_order");
+    if (rc) return rc;
+  } else {
+    // large meshes: the per-face kernels (a mesh spread over many workgroups, globally sorted schedule)
+    rc = ur_project_faces(verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, face_verts, stream);
+    if (rc) return rc;
+    rc = prep_faces(face_verts, NF, blur_radius, cull_backfaces, mesh_first_face, N, H, W, K, workspace, workspace_bytes,
+                    st, P);
+    if (rc) return rc;
+    if (zero_grad_face_verts && hipMemsetAsync(zero_grad_face_verts, 0, (size_t)NF * 36, st) != hipSuccess)
+      return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+    if (zero_grad_maps && hipMemsetAsync(zero_grad_maps, 0, (size_t)N * n_gmap * 4, st) != hipSuccess)
+      return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+  }
+  P.image = image; P.layers = layers;
+  return launch_raster<2>(P, st);
+}
+
+int ur_render_meshes_backward(const float* grad_image, const float* verts, const int64_t* faces,
+                              int64_t faces_mesh_stride, const float* R, const float* T, float sx, float sy, int N,
+                              int V, int F, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int H, int W,
+                              float blur_radius, int K, int clip_barycentric_coords, const float* maps,
+                              const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                              const float* background, const float* ambient, int mode, const int32_t* layers,
+                              const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                              float* grad_face_verts, float* grad_maps, int grads_are_zero, float* grad_verts,
+                              float* grad_R, float* grad_T, void* stream) {
+  if (N < 0 || F < 0 || Ht <= 0 || Wt <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  const int64_t NF = (int64_t)N * F;
+  const bool geometry = grad_verts || grad_R || grad_T;
+  if (geometry && !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "geometry gradients need the grad_face_verts buffer");
+  hipStream_t st = (hipStream_t)stream;
+  if (!grads_are_zero && N > 0) {
+    if (grad_face_verts && hipMemsetAsync(grad_face_verts, 0, (size_t)NF * 36, st) != hipSuccess)
+      return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+    if (grad_maps && hipMemsetAsync(grad_maps, 0, (size_t)N * Ht * Wt * 12, st) != hipSuccess)
+      return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+  }
+  int rc = ur_render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, N, NF, H, W, blur_radius, K,
+                                      clip_barycentric_coords, maps, face_uvs, face_uvs_shared, Ht, Wt, sigma, background,
+                                      ambient, mode, layers, workspace, workspace_bytes, scratch, scratch_bytes,
+                                      geometry ? grad_face_verts : nullptr, grad_maps, stream);
+  if (rc || !geometry) return rc;
+  return ur_project_faces_backward(verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts, grad_verts,
+                                   grad_R, grad_T, stream);
 }
 
 }  // extern "C"

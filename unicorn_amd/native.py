@@ -43,6 +43,11 @@ _SIGNATURES = {
     "ur_backward_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ur_render_layered_backward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
                                         _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "ur_render_meshes_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _i, _i, _f, _i, _i, _i,
+                                      _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ur_render_meshes_backward": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _i, _i, _f, _i, _i,
+                                       _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i,
+                                       _vp, _vp, _vp, _vp]),
     "ur_shade_blend_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i,
                                      _vp, _vp, _vp, _vp]),
 }
@@ -346,6 +351,81 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
             _ptr(gfv, None, True),
             _ptr(gmaps, None, True), _stream(maps)), "ur_render_layered_backward")
     return gfv, gmaps
+
+
+def _rgb_ptr(v):
+    return None if v is None else ctypes.cast(_rgb(v), _vp)
+
+
+def render_meshes_forward(verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_faces, image_size, blur_radius,
+                          faces_per_pixel, clip_barycentric_coords, maps, face_uvs, face_uvs_shared, sigma, background,
+                          ambient, mode, need_geometry_grads=False, need_map_grads=False, cull_backfaces=False):
+    """equal-sized meshes: camera + rasterizer + shader in one call.  -> image (N,4,H,W), face_verts (N*F,3,3),
+    layers, workspace, grads (one zero-filled float buffer holding the backward's two accumulators, or None)"""
+    N, V = verts.shape[:2]
+    F, fstride = _faces_layout(faces, N)
+    H, W = image_size
+    K = int(faces_per_pixel)
+    Ht, Wt = maps.shape[1:3]
+    dev = verts.device
+    NF = N * F
+    face_verts = torch.empty(NF, 3, 3, dtype=torch.float32, device=dev)
+    image = torch.empty(N, 4, H, W, dtype=torch.float32, device=dev)
+    layers = torch.empty(int(lib().ur_layers_elems(N, H, W, K)), dtype=torch.int32, device=dev)
+    ws = _workspace(NF, dev, N, H, W, K)
+    grads = gfv = gmaps = None
+    if need_geometry_grads or need_map_grads:
+        n_fv = NF * 9 if need_geometry_grads else 0
+        grads = torch.empty(n_fv + (maps.numel() if need_map_grads else 0), dtype=torch.float32, device=dev)
+        gfv = grads if need_geometry_grads else None
+        gmaps = grads[n_fv:] if need_map_grads else None
+    with _on(verts), _timed("ur_render_meshes_forward", verts):
+        _check(lib().ur_render_meshes_forward(
+            _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride, _ptr(R, torch.float32),
+            _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(mesh_first_face, torch.int64),
+            _ptr(mesh_num_faces, torch.int64), H, W, float(blur_radius), K, int(clip_barycentric_coords),
+            int(cull_backfaces), _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt,
+            float(sigma), _rgb_ptr(background), _rgb_ptr(ambient), int(mode), _ptr(face_verts), _ptr(image),
+            _ptr(layers), _ptr(gfv, None, True), _ptr(gmaps, None, True), _ptr(ws), ws.numel(), _stream(verts)),
+            "ur_render_meshes_forward")
+    return image, face_verts, layers, ws, grads
+
+
+def render_meshes_backward(grad_image, verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_faces, image_size,
+                           blur_radius, faces_per_pixel, clip_barycentric_coords, maps, face_uvs, face_uvs_shared, sigma,
+                           background, ambient, mode, layers, workspace, grads, need_verts, need_R, need_T, need_maps):
+    """-> grad_verts, grad_R, grad_T, grad_maps (None where not needed).  `grads`: the zero-filled buffer the forward
+    prepared for exactly these needs, or None (then one is cleared here)."""
+    N, V = verts.shape[:2]
+    F, fstride = _faces_layout(faces, N)
+    H, W = image_size
+    K = int(faces_per_pixel)
+    Ht, Wt = maps.shape[1:3]
+    dev = verts.device
+    NF = N * F
+    geometry = need_verts or need_R or need_T
+    n_fv = NF * 9 if geometry else 0
+    zero = grads is not None
+    if grads is None:
+        grads = torch.empty(n_fv + (maps.numel() if need_maps else 0), dtype=torch.float32, device=dev)
+    assert grads.numel() == n_fv + (maps.numel() if need_maps else 0)
+    gfv = grads if geometry else None
+    gmaps = grads[n_fv:].view(maps.shape) if need_maps else None
+    gv = torch.empty_like(verts) if need_verts else None
+    gR = torch.empty_like(R) if need_R else None
+    gT = torch.empty_like(T) if need_T else None
+    scratch = torch.empty(int(lib().ur_backward_scratch_bytes(N, H, W, K)), dtype=torch.uint8, device=dev)
+    with _on(verts), _timed("ur_render_meshes_backward", verts):
+        _check(lib().ur_render_meshes_backward(
+            _ptr(grad_image, torch.float32), _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
+            _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(mesh_first_face, torch.int64),
+            _ptr(mesh_num_faces, torch.int64), H, W, float(blur_radius), K, int(clip_barycentric_coords),
+            _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt, float(sigma),
+            _rgb_ptr(background), _rgb_ptr(ambient), int(mode), _ptr(layers, torch.int32), _ptr(workspace),
+            workspace.numel(), _ptr(scratch), scratch.numel(), _ptr(gfv, None, True), _ptr(gmaps, None, True),
+            int(zero), _ptr(gv, None, True), _ptr(gR, None, True), _ptr(gT, None, True), _stream(verts)),
+            "ur_render_meshes_backward")
+    return gv, gR, gT, gmaps
 
 
 def mesh_regularizers(verts, edge_quads, nbr_offsets, nbr_index, need_grad=True):

@@ -132,6 +132,44 @@ def render_layered(face_verts, maps, first, nfaces, image_size, blur_radius, K, 
                                 None if ambient is None else tuple(ambient), int(mode))
 
 
+class _RenderMeshes(Function):
+    """ur_render_meshes_forward / _backward: camera + rasterizer + shader of a batch of equal-sized meshes in one call
+    each way (MeshRenderer.forward, renderer.py:48-49).  The forward also clears the backward's gradient accumulators
+    (no fill launch in the backward) when it knows which gradients will be wanted."""
+
+    @staticmethod
+    def forward(ctx, verts, maps, R, T, faces, sx, sy, first, nfaces, image_size, blur_radius, K, clip, face_uvs,
+                shared, sigma, background, ambient, mode):
+        verts, maps, R, T = verts.contiguous(), maps.contiguous(), R.contiguous(), T.contiguous()
+        need_v, need_m, need_R, need_T = ctx.needs_input_grad[:4]
+        image, _, layers, ws, grads = native.render_meshes_forward(
+            verts, faces, R, T, sx, sy, first, nfaces, image_size, blur_radius, K, clip, maps, face_uvs, shared, sigma,
+            background, ambient, mode, need_geometry_grads=need_v or need_R or need_T, need_map_grads=need_m)
+        ctx.save_for_backward(verts, maps, R, T, faces, first, nfaces, face_uvs, layers, ws)
+        ctx.grads = grads
+        ctx.cfg = (sx, sy, image_size, blur_radius, K, clip, shared, sigma, background, ambient, mode)
+        return image
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_image):
+        verts, maps, R, T, faces, first, nfaces, face_uvs, layers, ws = ctx.saved_tensors
+        sx, sy, image_size, blur_radius, K, clip, shared, sigma, background, ambient, mode = ctx.cfg
+        need_v, need_m, need_R, need_T = ctx.needs_input_grad[:4]
+        grads, ctx.grads = ctx.grads, None  # cleared by the forward; a second backward (retain_graph) clears its own
+        gv, gR, gT, gmaps = native.render_meshes_backward(
+            grad_image.contiguous(), verts, faces, R, T, sx, sy, first, nfaces, image_size, blur_radius, K, clip, maps,
+            face_uvs, shared, sigma, background, ambient, mode, layers, ws, grads, need_v, need_R, need_T, need_m)
+        return (gv, gmaps, gR, gT) + (None,) * 15
+
+
+def render_meshes(verts, maps, R, T, faces, sx, sy, first, nfaces, image_size, blur_radius, K, clip, face_uvs, shared,
+                  sigma, background, ambient, mode):
+    return _RenderMeshes.apply(verts, maps, R, T, faces, float(sx), float(sy), first, nfaces, tuple(image_size),
+                               float(blur_radius), int(K), bool(clip), face_uvs, bool(shared), float(sigma),
+                               tuple(background), None if ambient is None else tuple(ambient), int(mode))
+
+
 def project_faces(verts, faces, R, T, sx, sy):
     return _ProjectFaces.apply(verts, faces, R, T, float(sx), float(sy))
 

@@ -164,13 +164,24 @@ class LayeredShader(nn.Module):
         bp = kwargs.get("blend_params", self.blend_params)
         rs = kwargs.get("raster_settings", rasterizer.raster_settings)
         tex = meshes.textures
-        face_verts, first, nf = rasterizer.transform(meshes, R, T)
         ambient = _rgb3(self.lights.ambient_color)
+        ambient = None if ambient == (1.0, 1.0, 1.0) else ambient
         face_uvs, shared = tex.faces_verts_uvs()
+        if meshes.equisized and not rs.cull_backfaces:
+            # the reference's case (one template topology): camera + rasterizer + shader in one call each way
+            sx, sy = rasterizer.cameras.focal_scale()
+            verts, faces = meshes.verts_padded(), meshes.faces_padded()
+            N, Fn = faces.shape[:2]
+            faces = faces[0] if faces.stride(0) == 0 else faces
+            first, nf = rasterizer._mesh_index(N, Fn, verts.device)
+            return ops.render_meshes(verts.float(), tex.maps_padded().float(), R.float(), T.float(), faces.contiguous(),
+                                     sx, sy, first, nf, rs.image_size, rs.blur_radius, rs.faces_per_pixel,
+                                     rs.clip_barycentric_coords, face_uvs.float(), shared, bp.sigma,
+                                     _rgb3(bp.background_color), ambient, self.blend_mode(bp))
+        face_verts, first, nf = rasterizer.transform(meshes, R, T)
         return ops.render_layered(face_verts, tex.maps_padded().float(), first, nf, rs.image_size, rs.blur_radius,
                                   rs.faces_per_pixel, rs.clip_barycentric_coords, face_uvs.float(), shared, bp.sigma,
-                                  _rgb3(bp.background_color), None if ambient == (1.0, 1.0, 1.0) else ambient,
-                                  self.blend_mode(bp))
+                                  _rgb3(bp.background_color), ambient, self.blend_mode(bp))
 
     def debug_outputs(self, colors, fragments, bp, image):
         """debug=True (renderer.py:199-200): the blend's intermediates next to the image -- colours with the
