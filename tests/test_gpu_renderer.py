@@ -346,3 +346,38 @@ def test_debug_returns_blend_intermediates():
     assert torch.all(colors[..., -1, :] == 1) and torch.all(alpha[..., -1] == 1) and torch.all(occ[..., 0] == 1)
     image.sum().backward()
     assert verts.grad is not None and maps.grad is not None
+
+
+def test_one_call_render_step_equals_the_composed_entry_points():
+    """ur_render_meshes_forward/backward (what Renderer.forward uses) against ur_project_faces + ur_render_layered_*
+    (+ ur_project_faces_backward), the route of batches of unequal meshes: same bits forward, same gradients"""
+    from unicorn_amd import ops
+    N, H, K = 3, 48, 12
+    sc, rend, meshes, (verts, maps, R, T) = _setup(N, 3, H, K, seed=31)
+    faces = sc["faces"].cuda()
+    fuv, shared = meshes.textures.faces_verts_uvs()
+    first, nf = rend.renderer.rasterizer._mesh_index(N, faces.shape[0], verts.device)
+    blur = orc.blur_radius_for(1e-4)
+    cot = torch.randn(N, 4, H, H, device=verts.device, generator=torch.Generator(device=verts.device).manual_seed(3))
+    one = ops.render_meshes(verts, maps, R, T, faces, S30, S30, first, nf, (H, H), blur, K, True, fuv, shared, 1e-4,
+                            (1.0, 1.0, 1.0), None, 1)
+    one.backward(cot)
+    g_one = [t.grad.clone() for t in (verts, maps, R, T)]
+    for t in (verts, maps, R, T):
+        t.grad = None
+    fv = ops.project_faces(verts, faces, R, T, S30, S30)
+    two = ops.render_layered(fv, maps, first, nf, (H, H), blur, K, True, fuv, shared, 1e-4, (1.0, 1.0, 1.0), None, 1)
+    two.backward(cot)
+    assert torch.equal(one.detach(), two.detach())
+    for a, t in zip(g_one, (verts, maps, R, T)):
+        assert rel_err(a.cpu().numpy(), t.grad.cpu().numpy()) <= 1e-5
+    # a second backward through the same graph (the forward's pre-cleared accumulators are used once only)
+    img = ops.render_meshes(verts, maps, R, T, faces, S30, S30, first, nf, (H, H), blur, K, True, fuv, shared, 1e-4,
+                            (1.0, 1.0, 1.0), None, 1)
+    for t in (verts, maps, R, T):
+        t.grad = None
+    img.backward(cot, retain_graph=True)
+    first_pass = verts.grad.clone()
+    verts.grad = None
+    img.backward(cot)
+    assert rel_err(verts.grad.cpu().numpy(), first_pass.cpu().numpy()) <= 1e-5
