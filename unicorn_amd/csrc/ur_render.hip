@@ -755,7 +755,22 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           colm &= livecols;
           rowm &= liverows;
           const int rw = __popc(colm), rh = __popc(rowm);
-          const int area = pass ? rw * rh : 0;
+          // Depth cull of whole faces: a face whose nearest corner lies behind the deepest hiding hit found so far at
+          // any pixel of its rectangle -- every pixel of the rectangle having one -- would be rejected pair by pair
+          // below; it gets no pairs at all.  (Snapshot taken once per chunk: hide depths only come nearer, pixels only
+          // become covered, so a stale snapshot errs on the safe side.)
+          bool behind = false;
+          if (can_cull) {
+            const unsigned long long hk0 = s_hide[lane];
+            const unsigned long long uncovered = __ballot(hk0 == ~0ull);
+            const int zb = wave_max(hk0 == ~0ull ? 0 : (int)(hk0 >> 32));  // depths are >= +0: bits order like ints
+            unsigned long long rows = (unsigned long long)rowm * 0x0101010101010101ull & 0x8040201008040201ull;
+            rows = (((rows + 0x7f7f7f7f7f7f7f7full) | rows) & 0x8080808080808080ull) >> 7;  // byte r = 1 iff row r
+            const unsigned long long rect = (rows * 0xffull) & ((unsigned long long)colm * 0x0101010101010101ull);
+            const float fzmin = (lane < cntc) ? rcs[lane * 5 + 4].w : 0.0f;
+            behind = (rect & uncovered) == 0ull && fzmin * 0.9999f > __int_as_float(zb);
+          }
+          const int area = (pass && !behind) ? rw * rh : 0;
           const unsigned long long m = __ballot(area > 0);
           const int nfp = __popcll(m);
           if (nfp > 0) {
