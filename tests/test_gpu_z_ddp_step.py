@@ -1,0 +1,79 @@
+"""the training step is data-parallel over the batch -- one process per GPU, DDP gradient all-reduce
+of the CNN / head parameters, no collective inside the renderer.  Two ranks (gloo, sharing the one GPU of the test
+box; on a node the same code runs with backend "nccl" = RCCL) each train on half of a batch with the alternate
+optimisation of unicorn.py:226-230 (unused parameters every step); the result must equal single-process training on
+the whole batch."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS, PER_RANK, IMG = 4, 2, 32
+
+
+def _make(device):
+    sys.path.insert(0, ROOT)
+    from examples.train_step import TinyUnicorn, synthetic_targets
+    torch.manual_seed(0)
+    model = TinyUnicorn(IMG, level=2, faces_per_pixel=10, tex_size=16, latent=32).to(device)
+    imgs = synthetic_targets(2 * PER_RANK, IMG, seed=5, device=device)
+    return model, imgs
+
+
+def _rank_main(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from examples.train_step import train_steps
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    model, imgs = _make(dev)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
+    losses = train_steps(ddp, imgs[rank * PER_RANK:(rank + 1) * PER_RANK], STEPS)
+    t = torch.tensor(losses, device=dev)
+    dist.all_reduce(t)
+    if rank == 0:
+        torch.save({"params": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                    "losses": (t / world).cpu()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_step_equals_single_process_training():
+    import torch.multiprocessing as mp
+    from examples.train_step import train_steps
+    with tempfile.TemporaryDirectory() as tmp:
+        out_path = os.path.join(tmp, "rank0.pt")
+        port = 29500 + (os.getpid() % 400)
+        ctx = mp.spawn(_rank_main, args=(2, port, out_path), nprocs=2, join=False)
+        for _ in range(150):                       # bounded wait: never hang the suite on a stuck rank
+            if ctx.join(timeout=1.0):
+                break
+        else:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("DDP ranks did not finish within 150 s")
+        # the same training in this process on the whole batch (after the ranks: three processes building their
+        # MIOpen kernels at the same time were seen to stall each other)
+        model, imgs = _make(torch.device("cuda", 0))
+        losses = train_steps(model, imgs, STEPS)
+        got = torch.load(out_path, weights_only=True)
+    np.testing.assert_allclose(got["losses"].numpy(), np.array(losses), rtol=1e-4)
+    assert losses[-1] < losses[0]
+    ref = model.state_dict()
+    for k, v in got["params"].items():
+        a, b = v.numpy(), ref[k].detach().cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-3), k
+    # both halves of the alternate optimisation moved their own parameters
+    torch.manual_seed(0)
+    from examples.train_step import TinyUnicorn
+    init = TinyUnicorn(IMG, level=2, faces_per_pixel=10, tex_size=16, latent=32).state_dict()
+    assert not torch.equal(init["pose.weight"], got["params"]["pose.weight"])
+    assert not torch.equal(init["texture.weight"], got["params"]["texture.weight"])

@@ -1,0 +1,2534 @@
+// ur_render.hip -- hand-written gfx950 (MI355X) kernels + the C ABI of include/unicorn_render.h.
+//
+// Execution model (DESIGN.md 5 has the long version):
+//   * k_face_prep: one thread per face -> bounding box, per-face record (corners, denominators, RN reciprocals), and
+//     a per-bin load count; k_bin_order sorts the 16x16-pixel bins of all meshes heaviest first;
+//   * k_raster<MODE>: one workgroup (4 waves) per bin, taken from that schedule.  Coarse step: the workgroup scans the
+//     mesh's face boxes (up to 8 coalesced float4 per lane), ballot + popcount prefix packs survivors into one bin
+//     list in LDS -- no atomics, deterministic; rounds of 2048 faces, the list cannot overflow.  Fine step: 64 bin
+//     faces at a time staged in LDS (double buffered).  MODE 0 (fragments): lane = pixel, faces walked one by one.
+//     MODE 2 (fused shading): (face, pixel) pairs dealt over the lanes, hits appended to per-pixel lists with LDS
+//     integer atomics.  MODE 1: tile lists exported;
+//   * per-pixel top-K: (depth, face) keys packed as u64 in LDS, [slot][pixel]; z >= 0, so unsigned order == (z, face)
+//     order; lists past the LDS cap continue in a global spill area;
+//   * MODE 2 tail: sort, (pixel, layer) items dealt over the lanes, UV sample + layered blend, layer records saved
+//     for k_render_bwd, which deals the same items again and scatters gradients through f64 LDS tables.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <vector>
+
+#include "../../include/unicorn_render.h"
+#include "ur_device.h"
+
+using namespace ur;
+
+extern "C" size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K);
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---- opt-in kernel timing (ur_profile_begin / ur_profile_end): HIP events recorded on the launch stream right around
+// the two dominant kernels.  Process-wide (the autograd engine runs the backward on another thread than the forward).
+struct ProfState {
+  std::vector<hipEvent_t> ev;   // 2 per slot: start, stop
+  std::vector<int> kind;        // UR_PROFILE_RASTER_FWD / UR_PROFILE_RENDER_BWD
+  std::atomic<int> next{0};
+  std::atomic<bool> on{false};
+};
+ProfState g_prof;
+
+struct ProfScope {  // records the slot's events around a kernel launch when profiling is on
+  hipStream_t st;
+  int slot = -1;
+  ProfScope(int kind, hipStream_t s) : st(s) {
+    if (!g_prof.on.load(std::memory_order_acquire)) return;
+    const int i = g_prof.next.fetch_add(1);
+    if (i >= (int)g_prof.kind.size()) return;
+    slot = i;
+    g_prof.kind[i] = kind;
+    (void)hipEventRecord(g_prof.ev[2 * i], st);
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  }
+};
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return UR_OK;
+}
+
+// Kernels that want more than 64 KB of dynamic LDS must be told so once per (kernel, device).  `slot` is a small
+// table per call site: the largest size configured so far on each device (process-wide, relaxed atomics: a race only
+// repeats the idempotent call).
+constexpr int kMaxDevices = 64;
+struct LdsSlot { std::atomic<size_t> done[kMaxDevices]; };
+
+int ensure_dynamic_lds(const void* kernel, size_t bytes, LdsSlot& slot) {
+  if (bytes <= 64 * 1024) return UR_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+  if (dev >= 0 && slot.done[dev].load(std::memory_order_relaxed) >= bytes) return UR_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+  if (dev >= 0) slot.done[dev].store(bytes, std::memory_order_relaxed);
+  return UR_OK;
+}
+
+// Wave-wide inclusive scans on the VALU's data-parallel-primitive lanes (row shifts inside a 16-lane row, then the
+// two row broadcasts): six VALU operations, where a __shfl_up ladder is six dependent trips through the LDS crossbar.
+// `ident` is the operation's neutral element (what a lane combines with when it has no source lane).
+#define UR_SCAN_STEP(CTRL, ROWMASK) v = op(v, __builtin_amdgcn_update_dpp(ident, v, CTRL, ROWMASK, 0xf, false))
+template <class Op> __device__ __forceinline__ int wave_scan(int v, int ident, Op op) {
+  UR_SCAN_STEP(0x111, 0xf);  // row_shr:1
+  UR_SCAN_STEP(0x112, 0xf);  // row_shr:2
+  UR_SCAN_STEP(0x114, 0xf);  // row_shr:4
+  UR_SCAN_STEP(0x118, 0xf);  // row_shr:8
+  UR_SCAN_STEP(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+  UR_SCAN_STEP(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+#undef UR_SCAN_STEP
+__device__ __forceinline__ int wave_scan_add(int v) {
+  return wave_scan(v, 0, [](int a, int b) { return a + b; });
+}
+__device__ __forceinline__ int wave_scan_max(int v) {  // v >= 0
+  return wave_scan(v, 0, [](int a, int b) { return max(a, b); });
+}
+// maximum over the wave of non-negative ints, in every lane
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_scan_max(v), 63); }
+// sum over the wave (valid in lane 63; summation order fixed by the scan network: deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+  return __int_as_float(wave_scan(__float_as_int(v), 0, [](int a, int b) {
+    return __float_as_int(__int_as_float(a) + __int_as_float(b)); }));
+}
+__device__ __forceinline__ float wave_fmin(float v) {
+  const int r = wave_scan(__float_as_int(v), __float_as_int(__builtin_inff()),
+                          [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); });
+  return __int_as_float(__builtin_amdgcn_readlane(r, 63));
+}
+__device__ __forceinline__ float wave_fmax(float v) {
+  const int r = wave_scan(__float_as_int(v), __float_as_int(-__builtin_inff()),
+                          [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); });
+  return __int_as_float(__builtin_amdgcn_readlane(r, 63));
+}
+
+constexpr int kPrepBins = 4096;  // bins per image the face-prep kernel counts in LDS (16 KB); beyond: global atomics
+
+// ------------------------------------------------------------------------------------------------------------------
+// face records
+// ------------------------------------------------------------------------------------------------------------------
+// One face: blur-expanded box, record, nearest depth (layout in ur_device.h).  Returns true when the face is culled.
+__device__ __forceinline__ bool face_record(const float c[9], float r, int cull, float4& bb, float4 rc[5]) {
+  const float v0x = c[0], v0y = c[1], z0 = c[2], v1x = c[3], v1y = c[4], z1 = c[5], v2x = c[6], v2y = c[7], z2 = c[8];
+  const float zmax = max_s(max_s(z0, z1), z2);
+  const float face_area = (v0x - v1x) * (v2y - v1y) - (v0y - v1y) * (v2x - v1x);  // edge(v0; v1, v2)
+  const bool culled = (zmax < kEps) || (face_area <= kEps && face_area >= -kEps) || (cull && face_area < 0.0f);
+  float xlo = min_s(min_s(v0x, v1x), v2x) - r, xhi = max_s(max_s(v0x, v1x), v2x) + r;
+  const float ylo = min_s(min_s(v0y, v1y), v2y) - r, yhi = max_s(max_s(v0y, v1y), v2y) + r;
+  if (culled) { xlo = __builtin_inff(); xhi = -__builtin_inff(); }
+  bb = make_float4(xlo, xhi, ylo, yhi);
+  const float denom = ((v2x - v0x) * (v1y - v0y) - (v2y - v0y) * (v1x - v0x)) + kEps;  // edge(v2; v0, v1) + eps
+  const float d01x = v1x - v0x, d01y = v1y - v0y, d12x = v2x - v1x, d12y = v2y - v1y;
+  const float d02x = v2x - v0x, d02y = v2y - v0y;
+  const float l01 = d01x * d01x + d01y * d01y, l02 = d02x * d02x + d02y * d02y, l12 = d12x * d12x + d12y * d12y;
+  rc[0] = make_float4(v0x, v0y, v1x, v1y);
+  rc[1] = make_float4(v2x, v2y, z0, z1);
+  rc[2] = make_float4(z2, denom, 1.0f / denom, l01);
+  rc[3] = make_float4(l02, l12, 1.0f / l01, 1.0f / l02);
+  rc[4] = make_float4(1.0f / l12, d12x, d12y, min_s(min_s(z0, z1), z2));
+  return culled;
+}
+
+// pixel rectangle (columns c0..c1, rows r0..r1, a pixel of slack either way) a blur-expanded box may touch: the load
+// estimate of the workgroup schedule counts +1 on every 16x16 bin it overlaps -- this only orders work, it decides
+// nothing
+__device__ __forceinline__ void box_pixels(const float4 bb, int H, int W, int& c0, int& c1, int& r0, int& r1) {
+  const float rx = (W > H) ? 2.0f * (float)W / (float)H : 2.0f, ry = (H > W) ? 2.0f * (float)H / (float)W : 2.0f;
+  // column c has x = rx/2 - rx (c + 0.5) / W  (+X left), row likewise
+  c0 = max(0, (int)floorf((0.5f * rx - bb.y) * (float)W / rx - 0.5f) - 1);
+  c1 = min(W - 1, (int)ceilf((0.5f * rx - bb.x) * (float)W / rx - 0.5f) + 1);
+  r0 = max(0, (int)floorf((0.5f * ry - bb.w) * (float)H / ry - 0.5f) - 1);
+  r1 = min(H - 1, (int)ceilf((0.5f * ry - bb.z) * (float)H / ry - 0.5f) + 1);
+}
+
+__global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv, int64_t NF, float r, int cull,
+                                                   float4* __restrict__ bbox, float4* __restrict__ rec,
+                                                   float* __restrict__ fz, const int64_t* __restrict__ first, int N,
+                                                   int H, int W, int* __restrict__ binload) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < NF;
+  bool culled = true;
+  float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (live) {
+    const float* p = fv + i * 9;
+    const float c[9] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
+    float4 rc[5];
+    culled = face_record(c, r, cull, bb, rc);
+    bbox[i] = bb;
+    fz[i] = rc[4].w;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) rec[5 * i + q] = rc[q];
+  }
+  // ---- load estimate for the workgroup schedule: +1 on every 16x16 bin the expanded box overlaps (a pixel of slack
+  //      either way -- this only orders the work, it decides nothing).  The workgroup first counts in LDS for the
+  //      mesh of its first face (consecutive faces nearly always share the mesh), then flushes the non-zero bins.
+  if (!binload) return;
+  const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nbins = nbx * nby;
+  __shared__ int s_load[kPrepBins];
+  __shared__ int s_mesh;
+  const bool use_lds = nbins <= kPrepBins;
+  if (use_lds) {
+    for (int j = threadIdx.x; j < nbins; j += 256) s_load[j] = 0;
+    if (threadIdx.x == 0) {
+      const int64_t i0 = (int64_t)blockIdx.x * blockDim.x;
+      int lo = 0, hi = N - 1;  // mesh of face i0: last n with first[n] <= i0
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= i0) lo = mid; else hi = mid - 1;
+      }
+      s_mesh = lo;
+    }
+    __syncthreads();
+  }
+  if (live && !culled) {
+    int lo = 0, hi = N - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (first[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    int c0, c1, r0, r1;
+    box_pixels(bb, H, W, c0, c1, r0, r1);
+    const bool local = use_lds && lo == s_mesh;
+    for (int by = r0 >> 4; by <= (r1 >> 4); ++by)
+      for (int bx = c0 >> 4; bx <= (c1 >> 4); ++bx) {
+        if (local) atomicAdd(&s_load[by * nbx + bx], 1);
+        else atomicAdd(&binload[(int64_t)lo * nbins + by * nbx + bx], 1);
+      }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < nbins; j += 256) {
+      const int v = s_load[j];
+      if (v) atomicAdd(&binload[(int64_t)s_mesh * nbins + j], v);
+    }
+  }
+}
+
+// Workgroup schedule: bins sorted by descending load estimate (counting sort over 256 load classes, one workgroup).
+// The long-running bins -- silhouettes, where many faces pile up -- then start first and the cheap ones fill the gaps
+// at the end, instead of a late heavy bin stretching the kernel.  Any permutation gives the same results.
+__global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binload, int n_bins, int* __restrict__ order,
+                                                    int parts, int bins_per_mesh) {
+  __shared__ int s_hist[256];
+  __shared__ int s_wsum[4];
+  __shared__ int s_max;
+  const int tid = threadIdx.x;
+  if (tid < 256) s_hist[tid] = 0;
+  if (tid == 0) s_max = 1;
+  // the first four loads of every thread stay in registers for the three passes (covers 4096 bins)
+  // load of bin i: binload[i], or -- when the per-mesh prep kernel left `parts` partial counts per mesh, laid out
+  // [mesh][part][bin] -- their sum
+  auto load_of = [&](int i) {
+    if (parts == 1) return binload[i];
+    const int m = i / bins_per_mesh, b = i - m * bins_per_mesh;
+    const int* p = binload + ((int64_t)m * parts) * bins_per_mesh + b;
+    int sum = 0;
+    for (int q0 = 0; q0 < parts; q0 += 8) {  // eight independent loads in flight
+      int t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = (q0 + u < parts) ? p[(int64_t)(q0 + u) * bins_per_mesh] : 0;
+      sum += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    return sum;
+  };
+  int v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = (tid + q * 1024 < n_bins) ? load_of(tid + q * 1024) : 0;
+  auto each = [&](auto fn) {  // fn(load, bin index) over this thread's bins
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (tid + q * 1024 < n_bins) fn(v[q], tid + q * 1024);
+    for (int i = tid + 4096; i < n_bins; i += 1024) fn(load_of(i), i);
+  };
+  __syncthreads();
+  int mx = 1;
+  each([&](int x, int) { mx = max(mx, x); });
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) atomicMax(&s_max, mx);
+  __syncthreads();
+  const float scale = 127.0f / (float)s_max;
+  // classes 0..127: loaded bins, heaviest first; classes 128..255: the empty bins, spread by index so that they do
+  // not all queue on one LDS counter
+  auto cls = [&](int x, int i) { return x <= 0 ? 128 + (i & 127) : 127 - min(127, (int)((float)x * scale)); };
+  each([&](int x, int i) { atomicAdd(&s_hist[cls(x, i)], 1); });
+  __syncthreads();
+  {  // exclusive prefix over the 256 classes: scan inside each of the first four waves, then add the waves before
+    const int h = tid < 256 ? s_hist[tid] : 0;
+    const int incl = wave_scan_add(h);
+    if (tid < 256 && (tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 256) {
+      int off = 0;
+      for (int w = 0; w < (tid >> 6); ++w) off += s_wsum[w];
+      s_hist[tid] = off + incl - h;
+    }
+  }
+  __syncthreads();
+  each([&](int x, int i) { order[atomicAdd(&s_hist[cls(x, i)], 1)] = i; });
+}
+
+// camera: view = X R + T, x_ndc = sx x / z, y_ndc = sy y / z, depth = view z (operation order fixed: part of the parity contract)
+__device__ __forceinline__ void project_vertex(const float* __restrict__ p, const float* __restrict__ r,
+                                               const float* __restrict__ t, float sx, float sy, float out[3]) {
+  const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
+  const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
+  const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
+  out[0] = (sx * vx) / vz;
+  out[1] = (sy * vy) / vz;
+  out[2] = vz;
+}
+
+constexpr int kMeshPrepMaxFaces = 8192;  // up to here the per-mesh prep kernel (<= 32 workgroups per mesh)
+
+// workgroups per mesh of k_project_prep_mesh = partial load counts per (mesh, bin); 1 when that kernel is not used
+__host__ __device__ inline int prep_parts(int64_t total_faces, int N) {
+  const int64_t F = N > 0 ? (total_faces + N - 1) / N : 0;
+  return (F > 0 && F <= kMeshPrepMaxFaces) ? (int)((F + 255) / 256) : 1;
+}
+
+// Equal-sized meshes (the reference's case: one template topology), ONE launch for everything that comes before the
+// schedule: camera projection + face gather (= k_project_faces), face records (= k_face_prep, same arithmetic, same
+// bits) and the per-bin load count.  Workgroup (part, mesh) takes 256 consecutive faces of its mesh, counts in LDS and
+// STORES its partial counts ([mesh][part][bin]; k_bin_order adds the parts up): no global atomics, nothing to zero
+// beforehand.  (A per-mesh sort interleaved rank by rank, which would also save the k_bin_order launch, was tried: it
+// costs the two big kernels 5 us each -- strict heaviest-first matters.)  Optionally the workgroups also clear their
+// share of the two gradient accumulators the backward will add into (saves the backward a fill launch).
+__global__ void __launch_bounds__(256) k_project_prep_mesh(
+    const float* __restrict__ verts, const int64_t* __restrict__ faces, int64_t fstride, const float* __restrict__ R,
+    const float* __restrict__ T, float sx, float sy, int N, int V, int F, float r, int cull, int H, int W,
+    float* __restrict__ face_verts, float4* __restrict__ bbox, float4* __restrict__ rec, float* __restrict__ fz,
+    int* __restrict__ binload, float* __restrict__ zero_a, int zero_a_n, float* __restrict__ zero_b, int zero_b_n) {
+  __shared__ int s_load[kPrepBins];
+  const int part = blockIdx.x, parts = gridDim.x, n = blockIdx.y, tid = threadIdx.x;
+  const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nbins = nbx * nby;
+  for (int j = tid; j < nbins; j += 256) s_load[j] = 0;
+  if (zero_a) {
+    float* z = zero_a + (int64_t)n * zero_a_n;
+    for (int j = part * 256 + tid; j < zero_a_n; j += parts * 256) z[j] = 0.0f;
+  }
+  if (zero_b) {
+    float* z = zero_b + (int64_t)n * zero_b_n;
+    for (int j = part * 256 + tid; j < zero_b_n; j += parts * 256) z[j] = 0.0f;
+  }
+  __syncthreads();
+  const int f = part * 256 + tid;
+  if (f < F) {
+    const float* rm = R + (int64_t)n * 9;
+    const float* tv = T + (int64_t)n * 3;
+    const int64_t* fc = faces + (int64_t)n * fstride + (int64_t)f * 3;
+    const float* vp = verts + (int64_t)n * V * 3;
+    float c[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int64_t vi = min(max(fc[k], (int64_t)0), (int64_t)V - 1);
+      project_vertex(vp + vi * 3, rm, tv, sx, sy, c + 3 * k);
+    }
+    const int64_t i = (int64_t)n * F + f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) face_verts[i * 9 + q] = c[q];
+    float4 bb, rc[5];
+    const bool culled = face_record(c, r, cull, bb, rc);
+    bbox[i] = bb;
+    fz[i] = rc[4].w;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) rec[5 * i + q] = rc[q];
+    if (!culled) {
+      int c0, c1, r0, r1;
+      box_pixels(bb, H, W, c0, c1, r0, r1);
+      for (int by = r0 >> 4; by <= (r1 >> 4); ++by)
+        for (int bx = c0 >> 4; bx <= (c1 >> 4); ++bx) atomicAdd(&s_load[by * nbx + bx], 1);
+    }
+  }
+  __syncthreads();
+  int* out = binload + ((int64_t)n * parts + part) * nbins;
+  for (int j = tid; j < nbins; j += 256) out[j] = s_load[j];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// rasterizer
+// ------------------------------------------------------------------------------------------------------------------
+struct RasterParams {
+  const float4* bbox;
+  const float4* rec;
+  const int64_t* first;
+  const float* fz;  // nearest corner depth per face
+  const int64_t* nfaces;
+  int N, H, W, K;
+  float blur;
+  int clip;
+  int nbx, nby;  // bins per row / column
+  int cap;       // K-list slots per lane held in LDS
+  int64_t total_faces;
+  const int* order;  // workgroup -> (mesh * bins + bin), heaviest bins first
+  unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
+  // outputs (fragments)
+  int32_t* p2f;
+  float* zbuf;
+  float* bary;
+  float* dists;
+  // tile-list export
+  int32_t* tl_counts;
+  int32_t* tl_lists;
+  int tl_cap;
+  // fused shading (MODE 2) and the fused backward
+  const float* maps;
+  const float* fuv;
+  int fuv_shared;
+  int Ht, Wt;
+  float sigma;
+  float bg[3];
+  float amb[3];
+  int use_amb;
+  int mode;
+  float* image;     // (N,4,H,W)
+  int32_t* layers;  // [N][TH][TW][K][6][64]: per tile, per depth slot, six 64-lane planes (lane = pixel): face index,
+                    // transmittance in front of the layer, alpha, colour r g b (float bits) of the layers that
+                    // matter for the blend, front to back, ended by face = -1 (unless all K slots are used)
+  float* scratch;   // backward: [N][TH][TW][K][2][64] per-layer (dL/dalpha, weight) handed from the per-pixel sweep
+                    // to the evenly dealt gradient pass
+  const float* gimage;
+  float* gmaps;
+  float* gfv;
+};
+
+// face-UV table row of packed face `fid` of mesh n
+__device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n, int fid) {
+  const int64_t fl = P.fuv_shared ? (int64_t)fid - P.first[n] : (int64_t)fid;
+  return P.fuv + fl * 6;
+}
+
+constexpr int kScanQ = 8;         // faces per lane per scan round
+constexpr int kBinCap = 256 * kScanQ;  // faces per scan round = bin-list entries (u16 offsets into the round)
+constexpr int kSub = 64;         // faces staged in LDS per fine step
+constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU (see raster_cap)
+constexpr int kPreStride = 96;   // ints per wave in the pair-prefix array: 65 prefix entries, then 64 byte marks
+
+// where the per-pixel layer counts start inside `layers` (after the [group][K][6][64] records)
+__host__ __device__ inline int64_t layer_counts_offset(int N, int nbx, int nby, int K) {
+  return (int64_t)N * nbx * nby * 4 * K * 6 * 64;
+}
+
+__device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float xc_hi, float yc_lo, float yc_hi) {
+  // bb = xlo xhi ylo yhi ; reject iff the whole centre interval is on one side of the box
+  return !(xc_hi < bb.x || xc_lo > bb.y || yc_hi < bb.z || yc_lo > bb.w);
+}
+
+// A key packs (depth bits, face index, hides-the-rest flag): unsigned order == (depth, face) order (depths are >= +0).
+__device__ __forceinline__ int key_face(unsigned long long k) { return (int)(((unsigned)(k & 0xffffffffull)) >> 1); }
+
+// The per-lane top-K list: the first `cap` slots live in LDS ([slot][lane], 8-byte lane stride: conflict free), the
+// rest (K > cap only, rare to be touched) in a global spill area of the same shape.
+struct KeyList {
+  unsigned long long* lds;    // + lane
+  unsigned long long* spill;  // + lane
+  int cap;
+  __device__ __forceinline__ unsigned long long get(int i) const {
+    return i < cap ? lds[(size_t)i * 64] : spill[(size_t)(i - cap) * 64];
+  }
+  __device__ __forceinline__ void put(int i, unsigned long long v) const {
+    if (i < cap) lds[(size_t)i * 64] = v; else spill[(size_t)(i - cap) * 64] = v;
+  }
+  // Keep, in order, the entries <= bound of this lane's first n entries (lanes with !need keep everything and
+  // return n); mx = the largest n among the lanes that need it (wave-uniform).  The spilled part is read eight
+  // entries at a time so that the global loads overlap instead of forming one dependent chain.
+  __device__ __forceinline__ int compact(bool need, int n, int mx, unsigned long long bound) const {
+    if (!need) n = 0;  // nothing to do in the loops below
+    int j = 0;
+    const int lds_n = mx < cap ? mx : cap;
+    for (int i = 0; i < lds_n; ++i)
+      if (i < n) {
+        const unsigned long long kk = lds[(size_t)i * 64];
+        if (kk <= bound) { put(j, kk); ++j; }
+      }
+    for (int i0 = cap; i0 < mx; i0 += 8) {
+      unsigned long long t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = (i0 + q < n) ? spill[(size_t)(i0 + q - cap) * 64] : ~0ull;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i0 + q < n && t[q] <= bound) { put(j, t[q]); ++j; }
+    }
+    return j;
+  }
+};
+
+// MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
+template <int MODE>
+__global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BW = 16, BH = 16, WPB = 4;
+  // LDS carve (kRasterFixedLds bytes, then the keys):
+  //   [bin list 2048 u16][wave counts 16 i32][per wave: 72 i32 pair prefix (reused as the item prefix of the fused
+  //   tail)][per wave: 64 u32 pair decode info][per wave: 64 i32 list lengths][per wave: 64 u64 hide keys]
+  //   [staged bbox 2x64 float4][staged records 2x320 float4][keys]
+  uint16_t* s_bin = reinterpret_cast<uint16_t*>(smem);
+  int32_t* s_wcnt = reinterpret_cast<int32_t*>(s_bin + kBinCap);
+  int32_t* s_fpre_all = s_wcnt + 16;
+  uint32_t* s_finfo_all = reinterpret_cast<uint32_t*>(s_fpre_all + 4 * kPreStride);
+  int32_t* s_cnt_all = reinterpret_cast<int32_t*>(s_finfo_all + 4 * 64);
+  unsigned long long* s_hide_all = reinterpret_cast<unsigned long long*>(s_cnt_all + 4 * 64);
+  float4* s_bb = reinterpret_cast<float4*>(s_hide_all + 4 * 64);
+  float4* s_rec = s_bb + 2 * kSub;
+  unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(s_rec + 2 * kSub * 5);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // workgroup schedule: heaviest bins first (k_bin_order)
+  const int item = P.order[blockIdx.x];
+  const int n = item / (P.nbx * P.nby);
+  const int b = item - n * (P.nbx * P.nby);
+  const int by = b / P.nbx, bx = b - by * P.nbx;
+  const int H = P.H, W = P.W, K = P.K;
+
+  // bin extents in pixel-centre NDC (columns x0..x1, rows y0..y1, clamped to the image)
+  const int bx0 = bx * BW, by0 = by * BH;
+  const int bx1 = min(W, bx0 + BW) - 1, by1 = min(H, by0 + BH) - 1;
+  const float bxc_hi = pix_to_ndc(W - 1 - bx0, W, H), bxc_lo = pix_to_ndc(W - 1 - bx1, W, H);
+  const float byc_hi = pix_to_ndc(H - 1 - by0, H, W), byc_lo = pix_to_ndc(H - 1 - by1, H, W);
+
+  // this wave's 64 pixels.  MODE 1 (tile lists): the 8x8 tile (wave & 1, wave >> 1) of the bin.  Otherwise every
+  // second column / row of the bin starting at (wave & 1, wave >> 1): the four waves of a workgroup then see almost
+  // the same load whatever the bin holds (a silhouette through one corner would otherwise leave three waves idle).
+  const int xs = (MODE == 1) ? 1 : 2;                 // pixel stride inside the wave
+  const int tx0 = bx0 + (wave & 1) * (MODE == 1 ? kTile : 1), ty0 = by0 + (wave >> 1) * (MODE == 1 ? kTile : 1);
+  const bool tile_live = (tx0 < W) && (ty0 < H);
+  const int tx1 = min(W, tx0 + xs * (kTile - 1) + 1) - 1, ty1 = min(H, ty0 + xs * (kTile - 1) + 1) - 1;
+  const float txc_hi = pix_to_ndc(W - 1 - tx0, W, H), txc_lo = pix_to_ndc(W - 1 - max(tx1, tx0), W, H);
+  const float tyc_hi = pix_to_ndc(H - 1 - ty0, H, W), tyc_lo = pix_to_ndc(H - 1 - max(ty1, ty0), H, W);
+
+  // this lane's pixel
+  const int x = tx0 + xs * (lane & 7), y = ty0 + xs * (lane >> 3);
+  const bool pix_live = (x < W) && (y < H);
+  const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
+
+  // index of this wave's pixel group in layers / spill / tile lists
+  const int64_t tile_id = (MODE == 1) ? ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * ((W + 7) / 8) + (tx0 >> 3)
+                                      : (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
+  KeyList keys;
+  keys.cap = P.cap;
+  keys.lds = s_keys_all + (size_t)wave * P.cap * 64 + lane;
+  keys.spill = P.spill + (tile_live ? tile_id : 0) * (int64_t)(K - P.cap) * 64 + lane;
+  int cnt = 0;       // entries in this lane's list
+  int tl_count = 0;  // MODE 1: faces appended to this tile's list (wave-uniform)
+  // MODE 2 only: depth of the nearest hit found so far that hides everything behind it (alpha == 1 and
+  // d(alpha)/d(dist) == 0).  A face whose nearest corner lies behind it cannot matter to this pixel's blend: its
+  // depth at the pixel is a convex combination of its corner depths (the clipped barycentrics are >= 0 and sum to 1).
+  float z_hide = __builtin_inff();
+  unsigned long long hide_key = ~0ull;  // smallest key among the hits that hide the rest
+  bool stale = false;                   // hide_key moved since this lane's list was last compacted
+  const bool can_cull = (MODE == 2) && (P.clip != 0 || P.blur == 0.0f);
+
+  // MODE 2 evaluates (face, pixel) PAIRS dealt out over the lanes (see the fine step); the per-pixel list length and
+  // hide key then live in LDS, where any lane can reach them with integer atomics.
+  int32_t* s_fpre = s_fpre_all + wave * kPreStride;
+  uint32_t* s_finfo = s_finfo_all + wave * 64;
+  int32_t* s_cnt = s_cnt_all + wave * 64;
+  unsigned long long* s_hide = s_hide_all + wave * 64;
+  unsigned long long* const lds_keys = s_keys_all + (size_t)wave * P.cap * 64;
+  unsigned long long* const spill_keys = P.spill + (tile_live ? tile_id : 0) * (int64_t)(K - P.cap) * 64;
+  unsigned long long last_hk = ~0ull;  // hide key this lane's list was last compacted against
+  bool any_stale = false;              // wave-uniform: some pixel's hide key moved since the last compaction
+  float pxc[8], pyc[8];                // the tile's 8 column / 8 row centres (wave-uniform)
+  unsigned livecols = 0, liverows = 0;
+  if (MODE == 2) {
+    s_cnt[lane] = 0;
+    s_hide[lane] = ~0ull;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pxc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), j));
+      pyc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), j * 8));
+      livecols |= (tx0 + xs * j < W) ? (1u << j) : 0u;
+      liverows |= (ty0 + xs * j < H) ? (1u << j) : 0u;
+    }
+  }
+
+  const int64_t f0 = P.first[n];
+  const int nf = (int)P.nfaces[n];
+
+  for (int rbase = 0; rbase < nf; rbase += kBinCap) {
+    // ---- coarse: the round's faces (up to 2048) are split evenly over the waves, wave w scans a contiguous range
+    //      (independent bbox loads per lane).  The survivors are packed into one bin list, nearer half first (by
+    //      nearest-corner depth against the midpoint of the bin's depth range), ascending face index inside each
+    //      half: the fused blend can then skip most of the far side of a closed mesh (z_hide below).  Order never
+    //      changes results -- selection is by (depth, face).
+    const int fbase = (int32_t)f0 + rbase;  // packed index of the round's first face: face = fbase + s_bin[i]
+    const int per = ((min(nf - rbase, kBinCap) + 255) >> 8) << 6;  // faces per wave (multiple of 64)
+    const int wbase = rbase + wave * per;
+    float4 bbv[kScanQ];
+    float zv[kScanQ];
+#pragma unroll
+    for (int q = 0; q < kScanQ; ++q) {
+      const int f = wbase + q * 64 + lane;
+      const bool in = (q * 64 < per) && (f < nf);
+      bbv[q] = in ? P.bbox[f0 + f] : make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
+      zv[q] = (MODE == 2 && in) ? P.fz[f0 + f] : 0.0f;
+    }
+    unsigned long long pm[kScanQ];
+    int wc = 0;
+    float zlo = __builtin_inff(), zhi = -__builtin_inff();
+#pragma unroll
+    for (int q = 0; q < kScanQ; ++q) {
+      const bool pass = bbox_overlap(bbv[q], bxc_lo, bxc_hi, byc_lo, byc_hi);
+      pm[q] = __ballot(pass);
+      wc += __popcll(pm[q]);
+      if (MODE == 2 && pass) { zlo = min_s(zlo, zv[q]); zhi = max_s(zhi, zv[q]); }
+    }
+    if (MODE == 2) {
+      zlo = wave_fmin(zlo);
+      zhi = wave_fmax(zhi);
+    }
+    if (lane == 0) {
+      s_wcnt[wave] = wc;
+      s_wcnt[8 + wave] = __float_as_int(zlo);
+      s_wcnt[12 + wave] = __float_as_int(zhi);
+    }
+    __syncthreads();
+    float zmid = __builtin_inff();
+    if (MODE == 2) {
+      float a = __builtin_inff(), b2 = -__builtin_inff();
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) {
+        a = fminf(a, __int_as_float(s_wcnt[8 + w]));
+        b2 = fmaxf(b2, __int_as_float(s_wcnt[12 + w]));
+      }
+      zmid = 0.5f * (a + b2);
+    }
+    unsigned long long nm[kScanQ];  // passing faces of the near half
+    int wn = 0;
+#pragma unroll
+    for (int q = 0; q < kScanQ; ++q) {
+      nm[q] = (MODE == 2) ? __ballot(((pm[q] >> lane) & 1ull) && zv[q] <= zmid) : pm[q];
+      wn += __popcll(nm[q]);
+    }
+    if (lane == 0) s_wcnt[4 + wave] = wn;
+    __syncthreads();
+    int list_n = 0, near_n = 0, pre_all = 0, pre_near = 0;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) {
+      const int c = s_wcnt[w], cn = s_wcnt[4 + w];
+      pre_all += (w < wave) ? c : 0;
+      pre_near += (w < wave) ? cn : 0;
+      list_n += c;
+      near_n += cn;
+    }
+    {
+      int pos_near = pre_near, pos_far = near_n + (pre_all - pre_near);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int q = 0; q < kScanQ; ++q) {
+        const unsigned long long fm = pm[q] & ~nm[q];
+        const uint16_t fid = (uint16_t)(wave * per + q * 64 + lane);
+        if ((nm[q] >> lane) & 1ull) s_bin[pos_near + __popcll(nm[q] & lt)] = fid;
+        else if ((fm >> lane) & 1ull) s_bin[pos_far + __popcll(fm & lt)] = fid;
+        pos_near += __popcll(nm[q]);
+        pos_far += __popcll(fm);
+      }
+    }
+    __syncthreads();
+    if (list_n == 0) continue;
+
+    // ---- fine: 64 bin faces at a time; their bboxes / records are staged in LDS by the whole workgroup (next step's
+    //      global loads are in flight while this step is evaluated), each wave walks the ones that touch its tile
+    const int nsub = (list_n + kSub - 1) / kSub;
+    float4 r_bb = make_float4(0, 0, 0, 0), r_r0 = r_bb, r_r1 = r_bb;
+    auto stage_load = [&](int c) {
+      const int cntc = min(kSub, list_n - c * kSub);
+      if (tid < cntc) r_bb = P.bbox[fbase + s_bin[c * kSub + tid]];
+      if (tid < cntc * 5) r_r0 = P.rec[5 * (size_t)(fbase + s_bin[c * kSub + tid / 5]) + tid % 5];
+      if (tid + 256 < cntc * 5) r_r1 = P.rec[5 * (size_t)(fbase + s_bin[c * kSub + (tid + 256) / 5]) + (tid + 256) % 5];
+    };
+    auto stage_write = [&](int c) {
+      const int cntc = min(kSub, list_n - c * kSub);
+      float4* bb = s_bb + (c & 1) * kSub;
+      float4* rc = s_rec + (c & 1) * kSub * 5;
+      if (tid < cntc) bb[tid] = r_bb;
+      if (tid < cntc * 5) rc[tid] = r_r0;
+      if (tid + 256 < cntc * 5) rc[tid + 256] = r_r1;
+    };
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    // one face of the staged chunk against this lane's own pixel (lane = pixel); list state in registers
+    auto lockstep_face = [&](int c, int src, const float4* bbs, const float4* rcs) {
+      const int ufid = fbase + s_bin[c * kSub + src];  // wave-uniform
+      const float4 ubb = bbs[src];
+      const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
+                                  rcs[src * 5 + 4]);
+      bool hit = pix_live && !(px < ubb.x || px > ubb.y || py < ubb.z || py > ubb.w);
+      if (can_cull) hit = hit && !(fc.zmin * 0.9999f > z_hide);
+      Eval ev;
+      if (hit) hit = eval_face(fc, px, py, P.blur, P.clip != 0, ev);
+      if (hit) {
+        const bool hides = (MODE == 2) && hides_rest(ev.sd, P.sigma, P.mode);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
+                                       ((unsigned)ufid << 1) | (hides ? 1u : 0u);
+        if (hides && key < hide_key) { z_hide = ev.pz; hide_key = key; stale = true; }
+        if (MODE == 2 && stale && cnt >= P.cap && key <= hide_key) {
+          // about to leave LDS (or full): first throw out what the nearest hiding hit has made irrelevant
+          int j = 0;
+          for (int i = 0; i < cnt; ++i) {
+            const unsigned long long kk = keys.get(i);
+            if (kk <= hide_key) { keys.put(j, kk); ++j; }
+          }
+          cnt = j;
+          stale = false;
+        }
+        if (MODE == 2 && key > hide_key) {
+          // behind a hit that hides the rest: irrelevant to the blend
+        } else if (cnt < K) {
+          keys.put(cnt, key);
+          ++cnt;
+        } else {
+          // list full: replace the current maximum when the newcomer is smaller (rare path)
+          unsigned long long mx = 0;
+          int im = 0;
+          for (int i = 0; i < K; ++i) {
+            const unsigned long long kk = keys.get(i);
+            if (kk > mx) { mx = kk; im = i; }
+          }
+          if (key < mx) keys.put(im, key);
+        }
+      }
+    };
+
+    for (int c = 0; c < nsub; ++c) {
+      if (c + 1 < nsub) stage_load(c + 1);
+      if (tile_live) {
+        const int cntc = min(kSub, list_n - c * kSub);
+        const float4* bbs = s_bb + (c & 1) * kSub;
+        const float4* rcs = s_rec + (c & 1) * kSub * 5;
+        float4 mybb = make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
+        if (lane < cntc) mybb = bbs[lane];
+        const bool pass = (lane < cntc) && bbox_overlap(mybb, txc_lo, txc_hi, tyc_lo, tyc_hi);
+        if (MODE == 1) {
+          const unsigned long long m = __ballot(pass);
+          if (pass) {
+            const int pos = tl_count + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < P.tl_cap) P.tl_lists[tile_id * P.tl_cap + pos] = fbase + s_bin[c * kSub + lane];
+          }
+          tl_count += __popcll(m);
+        } else if (MODE == 0) {
+          unsigned long long m = __ballot(pass);
+          while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            lockstep_face(c, src, bbs, rcs);
+          }
+        } else {
+          // ---- MODE 2: a face of this mesh size covers a third of a tile's pixels, so walking faces with lane =
+          //      pixel leaves two lanes in three idle.  Instead every lane first takes one FACE of the chunk and
+          //      finds the rectangle of tile pixels inside its blur-expanded box (the very comparisons a pixel would
+          //      make, on the tile's 8 column / 8 row centres); the (face, pixel) pairs of all rectangles are then
+          //      numbered by a prefix sum and evaluated 64 at a time, whole faces per batch.  A hit is appended to
+          //      its pixel's list with an LDS integer atomic; list order is irrelevant (sorted by key in the tail).
+          unsigned colm = 0, rowm = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            colm |= !(pxc[j] < mybb.x || pxc[j] > mybb.y) ? (1u << j) : 0u;
+            rowm |= !(pyc[j] < mybb.z || pyc[j] > mybb.w) ? (1u << j) : 0u;
+          }
+          colm &= livecols;
+          rowm &= liverows;
+          const int rw = __popc(colm), rh = __popc(rowm);
+          // Depth cull of whole faces: a face whose nearest corner lies behind the deepest hiding hit found so far at
+          // any pixel of its rectangle -- every pixel of the rectangle having one -- would be rejected pair by pair
+          // below; it gets no pairs at all.  (Snapshot taken once per chunk: hide depths only come nearer, pixels only
+          // become covered, so a stale snapshot errs on the safe side.)
+          bool behind = false;
+          if (can_cull) {
+            const unsigned long long hk0 = s_hide[lane];
+            const unsigned long long uncovered = __ballot(hk0 == ~0ull);
+            const int zb = wave_max(hk0 == ~0ull ? 0 : (int)(hk0 >> 32));  // depths are >= +0: bits order like ints
+            unsigned long long rows = (unsigned long long)rowm * 0x0101010101010101ull & 0x8040201008040201ull;
+            rows = (((rows + 0x7f7f7f7f7f7f7f7full) | rows) & 0x8080808080808080ull) >> 7;  // byte r = 1 iff row r
+            const unsigned long long rect = (rows * 0xffull) & ((unsigned long long)colm * 0x0101010101010101ull);
+            const float fzmin = (lane < cntc) ? rcs[lane * 5 + 4].w : 0.0f;
+            behind = (rect & uncovered) == 0ull && fzmin * 0.9999f > __int_as_float(zb);
+          }
+          const int area = (pass && !behind) ? rw * rh : 0;
+          const unsigned long long m = __ballot(area > 0);
+          const int nfp = __popcll(m);
+          if (nfp > 0) {
+            const int incl = wave_scan_add(area);
+            const int total_pairs = __builtin_amdgcn_readlane(incl, 63);
+            if (area > 0) {
+              const int rank = __popcll(m & ((1ull << lane) - 1ull));
+              s_fpre[rank] = incl - area;
+              // decode word: chunk slot, rectangle origin, width and ceil(2^15 / width) (q / width for q < 64)
+              s_finfo[rank] = (unsigned)lane | ((unsigned)(__ffs(colm) - 1) << 6) | ((unsigned)(__ffs(rowm) - 1) << 9) |
+                              ((unsigned)rw << 12) | ((unsigned)((32768 + rw - 1) / rw) << 16);
+            }
+            if (lane + 1 >= nfp) s_fpre[lane + 1] = (lane + 1 == nfp) ? total_pairs : 0x7fffffff;
+            // compacted view: lane r holds the r-th face that has pairs
+            const int cpre = s_fpre[lane], cend = s_fpre[lane + 1];
+            const unsigned cinfo = s_finfo[lane];
+            const int lim = min(P.cap, K);
+            int r0 = 0;
+            while (r0 < nfp) {
+              // how many faces can go the pair way: each adds at most one entry to any pixel's list, and no list
+              // may pass K (there the exact keep-the-K-smallest rule takes over, lane = pixel)
+              int c2 = s_cnt[lane];
+              int cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
+              if (any_stale && cmax + (nfp - r0) > lim) {
+                // compact the lists whose hide key moved: drop what the nearest hiding hit made irrelevant
+                const unsigned long long hk = s_hide[lane];
+                const bool need = (hk != last_hk) && c2 > 0;
+                const int mx = __builtin_amdgcn_readfirstlane(wave_max(need ? c2 : 0));
+                const int j = keys.compact(need, c2, mx, hk);
+                if (need) { c2 = j; s_cnt[lane] = c2; }
+                last_hk = hk;
+                any_stale = false;
+                cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
+              }
+              const int room = K - cmax;
+              if (room < min(nfp - r0, 4)) {
+                const int r1 = min(nfp, r0 + 8);
+                cnt = c2;
+                hide_key = s_hide[lane];
+                z_hide = (hide_key == ~0ull) ? __builtin_inff() : __uint_as_float((unsigned)(hide_key >> 32));
+                stale = hide_key != last_hk;
+                for (int r = r0; r < r1; ++r)
+                  lockstep_face(c, __builtin_amdgcn_readlane((int)cinfo, r) & 63, bbs, rcs);
+                s_cnt[lane] = cnt;
+                s_hide[lane] = hide_key;
+                if (!stale) last_hk = hide_key;
+                any_stale = any_stale || __any(stale);
+                r0 = r1;
+                continue;
+              }
+              const int r1 = r0 + min(nfp - r0, room);
+              const int pbeg = __builtin_amdgcn_readlane(cpre, r0), pend = __builtin_amdgcn_readlane(cend, r1 - 1);
+              bool improved = false;
+              for (int pb = pbeg; pb < pend; pb += 64) {
+                const int pidx = pb + lane;
+                const bool act = pidx < pend;
+                // which face does pair pidx belong to?  The faces that start inside the batch mark their first
+                // pair's slot with their rank + 1, slot 0 takes the face that holds pair pb, and a running maximum
+                // spreads the marks to the right.
+                unsigned char* marks = reinterpret_cast<unsigned char*>(s_fpre + 68);
+                marks[lane] = 0;
+                const bool mine = lane >= r0 && lane < r1 && cend > pb && cpre < pb + 64;
+                const int rfirst = __builtin_ctzll(__ballot(mine));
+                if (mine && cpre > pb) marks[cpre - pb] = (unsigned char)(lane + 1);
+                const int rr = wave_scan_max(lane == 0 ? rfirst + 1 : (int)marks[lane]) - 1;
+                const int mypre = s_fpre[rr];
+                const unsigned info = s_finfo[rr];
+                const int q = pidx - mypre;
+                const int w = (int)((info >> 12) & 15u);
+                const int dy = (q * (int)(info >> 16)) >> 15, dx = q - dy * w;
+                const int src = (int)(info & 63u);
+                const int pl = act ? ((((int)((info >> 9) & 7u) + dy) << 3) | ((int)((info >> 6) & 7u) + dx)) : lane;
+                const float qx = __shfl(px, pl, 64), qy = __shfl(py, pl, 64);
+                if (act) {
+                  const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
+                                              rcs[src * 5 + 4]);
+                  unsigned long long hk = s_hide[pl];
+                  bool hit = true;
+                  if (can_cull && hk != ~0ull) hit = !(fc.zmin * 0.9999f > __uint_as_float((unsigned)(hk >> 32)));
+                  Eval ev;
+                  if (hit) hit = eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
+                  if (hit) {
+                    const bool hides = hides_rest(ev.sd, P.sigma, P.mode);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
+                                                   ((unsigned)(fbase + s_bin[c * kSub + src]) << 1) | (hides ? 1u : 0u);
+                    if (hides && key < hk) { atomicMin(&s_hide[pl], key); hk = key; improved = true; }
+                    if (key <= hk) {
+                      const int slot = atomicAdd(&s_cnt[pl], 1);
+                      if (slot < P.cap) lds_keys[(size_t)slot * 64 + pl] = key;
+                      else spill_keys[(size_t)(slot - P.cap) * 64 + pl] = key;
+                    }
+                  }
+                }
+              }
+              any_stale = any_stale || __any(improved);
+              r0 = r1;
+            }
+          }
+        }
+      }
+      if (c + 1 < nsub) stage_write(c + 1);
+      __syncthreads();
+    }
+  }
+
+  if (MODE == 1) {
+    if (tile_live) {
+      if (lane == 0) P.tl_counts[tile_id] = tl_count;
+      for (int i = tl_count + lane; i < P.tl_cap; i += 64) P.tl_lists[tile_id * P.tl_cap + i] = -1;
+    }
+    return;
+  }
+  if (!tile_live) return;
+
+  if (MODE == 2) {
+    // ---- fused shading.  (a) per pixel: drop the hits behind the nearest one that hides the rest, sort what is left
+    //      front to back (in place; that hit, if any, comes last);  (b) the (pixel, layer) items of the whole tile
+    //      are dealt out evenly over the 64 lanes -- any lane can evaluate any item -- so every lane stays busy
+    //      although pixels have very different depths;  (c) each pixel pulls its items' (alpha, colour) back from
+    //      the lanes that computed them, in depth order, and composites: the arithmetic and its order are exactly
+    //      those of a per-pixel loop, so the image is bit-identical to the two-stage path.
+    const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+    unsigned long long* lds_base = lds_keys;
+    unsigned long long* spill_base = spill_keys;
+    cnt = s_cnt[lane];
+    hide_key = s_hide[lane];
+    int n_rel = cnt;
+    if (__any(hide_key != ~0ull && cnt > 0)) {
+      const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(hide_key != ~0ull ? cnt : 0));
+      const int j = keys.compact(hide_key != ~0ull, cnt, maxcnt, hide_key);
+      if (hide_key != ~0ull) n_rel = j;
+    }
+    if (!pix_live) n_rel = 0;
+    constexpr int kDeep = 8;
+    {
+      // short lists: per-lane selection sort
+      const bool mine = n_rel <= kDeep || n_rel > 64;
+      int sorted = 0;
+      while (__any(mine && sorted < n_rel - 1)) {
+        if (mine && sorted < n_rel - 1) {
+          unsigned long long best = keys.get(sorted);
+          const unsigned long long cur = best;
+          int ib = sorted;
+          for (int i = sorted + 1; i < n_rel; ++i) {
+            const unsigned long long kk = keys.get(i);
+            if (kk < best) { best = kk; ib = i; }
+          }
+          if (ib != sorted) { keys.put(ib, cur); keys.put(sorted, best); }
+          ++sorted;
+        }
+      }
+      // long lists (pixels in the blur halo of a silhouette vertex): the whole wave sorts one list at a time by
+      // rank counting -- lane j holds entry j, the list is broadcast entry by entry, no memory access in the loop
+      unsigned long long deep = __ballot(!mine);
+      while (deep) {
+        const int l = __builtin_ctzll(deep);
+        deep &= deep - 1;
+        const int ml = __builtin_amdgcn_readlane(n_rel, l);
+        unsigned long long kj = ~0ull;
+        if (lane < ml)
+          kj = (lane < P.cap) ? lds_base[(size_t)lane * 64 + l] : spill_base[(size_t)(lane - P.cap) * 64 + l];
+        const unsigned lo = (unsigned)kj, hi = (unsigned)(kj >> 32);
+        int rank = 0;
+        for (int i = 0; i < ml; ++i) {
+          const unsigned long long ki = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, i) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)lo, i);
+          rank += (ki < kj) ? 1 : 0;
+        }
+        if (lane < ml) {
+          if (rank < P.cap) lds_base[(size_t)rank * 64 + l] = kj;
+          else spill_base[(size_t)(rank - P.cap) * 64 + l] = kj;
+        }
+      }
+    }
+    const int m = n_rel;  // layers of this pixel that matter, front to back in slots [0, m)
+    const int incl = wave_scan_add(m);
+    const int pre = incl - m;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int* s_pre = s_fpre_all + wave * kPreStride;
+    unsigned char* marks = reinterpret_cast<unsigned char*>(s_pre + 68);
+    s_pre[lane] = pre;
+    // the staging buffers are dead once the fine step is over (every wave is past its last barrier): this wave's
+    // slice of them carries the batch's (alpha, r, g, b) from the lanes that computed them to the pixels' owners
+    float4* s_res = s_rec + wave * 64;
+    int32_t* lay_tile = P.layers + tile_id * (int64_t)K * 6 * 64;  // [K][6 words][64 lanes]
+    int32_t* lay = lay_tile + lane;
+    float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+    for (int base = 0; base < total; base += 64) {
+      const int item = base + lane;
+      // owner of item: the pixels whose first item falls inside the batch mark that slot with lane + 1, slot 0 takes
+      // the pixel that holds item `base`, and a running maximum spreads the marks to the right
+      marks[lane] = 0;
+      const int l0 = 63 - __builtin_clzll(__ballot(m > 0 && pre <= base));
+      if (m > 0 && pre > base && pre < base + 64) marks[pre - base] = (unsigned char)(lane + 1);
+      const int l = wave_scan_max(lane == 0 ? l0 + 1 : (int)marks[lane]) - 1;
+      float va = 0.0f, vr = 0.0f, vg = 0.0f, vb = 0.0f;
+      if (item < total) {
+        const int k = item - s_pre[l];
+        const unsigned long long key = (k < P.cap) ? lds_base[(size_t)k * 64 + l]
+                                                    : spill_base[(size_t)(k - P.cap) * 64 + l];
+        const int fid = key_face(key);
+        const float qx = pix_to_ndc(W - 1 - (tx0 + xs * (l & 7)), W, H);
+        const float qy = pix_to_ndc(H - 1 - (ty0 + xs * (l >> 3)), H, W);
+        const Face fc = load_face(P.rec, fid);
+        const float* fu = face_uv_row(P, n, fid);
+        const float fu0 = fu[0], fu1 = fu[1], fu2 = fu[2], fu3 = fu[3], fu4 = fu[4], fu5 = fu[5];
+        Eval ev;
+        eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
+        va = layer_alpha(ev.sd, true, P.sigma, P.mode);
+        const float u = (ev.c0 * fu0 + ev.c1 * fu2) + ev.c2 * fu4;
+        const float v = (ev.c0 * fu1 + ev.c1 * fu3) + ev.c2 * fu5;
+        const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+        sample_rgb(map, bl, P.Ht, P.Wt, vr, vg, vb);
+        if (P.use_amb) { vr *= P.amb[0]; vg *= P.amb[1]; vb *= P.amb[2]; }
+        // the layer record for the backward, written by whoever computed it (plane 1, the transmittance in front of
+        // the layer, comes from the pixel's owner below)
+        int32_t* le = lay_tile + (int64_t)k * 6 * 64 + l;
+        le[0] = fid;
+        le[128] = __float_as_int(va);
+        le[192] = __float_as_int(vr);
+        le[256] = __float_as_int(vg);
+        le[320] = __float_as_int(vb);
+      }
+      s_res[lane] = make_float4(va, vr, vg, vb);
+      // owners composite their items of this batch, in depth order
+      const int s0 = max(pre, base), e0 = min(pre + m, base + 64);
+      const int nloop = __builtin_amdgcn_readfirstlane(wave_max(max(e0 - s0, 0)));
+      for (int t = 0; t < nloop; ++t) {
+        if (s0 + t < e0) {
+          const float4 c = s_res[s0 + t - base];
+          lay[(int64_t)(s0 + t - pre) * 6 * 64 + 64] = __float_as_int(occ);
+          r += occ * c.x * c.y; g += occ * c.x * c.z; b += occ * c.x * c.w;
+          occ = occ * (1.0f - c.x);
+        }
+      }
+    }
+    P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] = m;  // per-pixel layer count
+    if (pix_live) {
+      const int64_t hw = (int64_t)H * W;
+      float* img = P.image + (int64_t)n * 4 * hw + (int64_t)y * W + x;
+      img[0] = r + occ * 1.0f * P.bg[0];
+      img[hw] = g + occ * 1.0f * P.bg[1];
+      img[2 * hw] = b + occ * 1.0f * P.bg[2];
+      img[3 * hw] = 1.0f - occ;
+    }
+    return;
+  }
+
+  // ---- output: ascending extraction, winners re-evaluated ----------------------------------------------------
+  const int64_t ebase = (((int64_t)n * H + y) * W + x) * K;
+  unsigned long long last_key = 0;
+  bool first_take = true;
+  const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(cnt));
+  for (int k = 0; k < maxcnt; ++k) {
+    if (k < cnt) {
+      unsigned long long best = ~0ull;
+      for (int i = 0; i < cnt; ++i) {
+        const unsigned long long kk = keys.get(i);
+        if ((first_take || kk > last_key) && kk < best) best = kk;
+      }
+      last_key = best;
+      first_take = false;
+      const int fid = key_face(best);
+      const Face fc = load_face(P.rec, fid);
+      Eval ev;
+      eval_face(fc, px, py, P.blur, P.clip != 0, ev);
+      P.p2f[ebase + k] = fid;
+      if (P.zbuf) P.zbuf[ebase + k] = __uint_as_float((unsigned)(best >> 32));
+      if (P.dists) P.dists[ebase + k] = ev.sd;
+      if (P.bary) {
+        P.bary[(ebase + k) * 3 + 0] = ev.c0;
+        P.bary[(ebase + k) * 3 + 1] = ev.c1;
+        P.bary[(ebase + k) * 3 + 2] = ev.c2;
+      }
+    }
+  }
+  // padding: for every pixel of the tile the slots [cnt, K) are written by lanes that sweep k (contiguous stores)
+  for (int p = 0; p < 64; ++p) {
+    const int pcnt = __builtin_amdgcn_readlane(cnt, p);
+    const int qx = tx0 + xs * (p & 7), qy = ty0 + xs * (p >> 3);
+    if (qx >= W || qy >= H) continue;
+    const int64_t qbase = (((int64_t)n * H + qy) * W + qx) * K;
+    for (int k = pcnt + lane; k < K; k += 64) {
+      P.p2f[qbase + k] = -1;
+      if (P.zbuf) P.zbuf[qbase + k] = -1.0f;
+      if (P.dists) P.dists[qbase + k] = -1.0f;
+    }
+    if (P.bary)
+      for (int k3 = pcnt * 3 + lane; k3 < K * 3; k3 += 64) P.bary[qbase * 3 + k3] = -1.0f;
+  }
+}
+
+// 64-pixel groups (one per wave) of an image: 4 per 16x16 bin
+size_t wave_groups(int H, int W) { return (size_t)((H + 15) / 16) * ((W + 15) / 16) * 4; }
+
+constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4 + 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 8 +
+                                   2 * kSub * 16 + 2 * kSub * 5 * 16;
+
+// K-list slots per pixel kept in LDS (the rest spills to global memory).  Four workgroups per CU (40 KB each) is the
+// best trade for the headline meshes, whose per-pixel lists are short; where many small faces fall inside every
+// pixel's blur disc the lists run deep and LDS residency pays more than occupancy (measured: 5120 faces at 128^2
+// +9 % with three workgroups per CU, 20480 faces at 256^2 / K=100 +12 % with two), so the budget follows the mesh's
+// face density on the image: faces per pixel >= 0.2 -> three workgroups per CU, and two when K > 64 as well.
+int raster_cap(int64_t total_faces, int N, int H, int W, int K) {
+  const double density = (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W);
+  const size_t budget = density < 0.2 ? (size_t)kLdsBudget : (K > 64 ? (size_t)80 * 1024 : (size_t)52 * 1024);
+  const int fit = (int)((budget - kRasterFixedLds) / (4 * 64 * 8));
+  return K < fit ? K : fit;
+}
+
+size_t raster_spill_bytes(int64_t total_faces, int N, int H, int W, int K) {
+  const int over = K - raster_cap(total_faces, N, H, W, K);
+  return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
+}
+
+template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
+  P.nbx = (P.W + 15) / 16;
+  P.nby = (P.H + 15) / 16;
+  P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K);
+  const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
+  static LdsSlot lds_slot;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE>), lds, lds_slot)) return rc;
+  const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
+  if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
+  {
+    ProfScope prof(MODE == 2 ? UR_PROFILE_RASTER_FWD : UR_PROFILE_OTHER, st);
+    hipLaunchKernelGGL((k_raster<MODE>), dim3((unsigned)blocks), dim3(256), lds, st, P);
+  }
+  return check_launch("k_raster");
+}
+
+// workspace = [bbox: NF float4][records: NF x 5 float4][nearest depth: NF float, padded to 16 B]
+//             [schedule: N * bins int, padded to 16 B][bin loads: N * bins int, padded, x prep_parts][K-list spill]
+size_t sched_ints(int N, int H, int W) { return (((size_t)N * ((H + 15) / 16) * ((W + 15) / 16)) + 3) / 4 * 4; }
+
+const int* sched_order(const void* ws, int64_t NF, int N, int H, int W) {
+  const float* fz = reinterpret_cast<const float*>(reinterpret_cast<const float4*>(ws) + 6 * NF);
+  return reinterpret_cast<const int*>(fz + ((NF + 3) / 4) * 4);
+}
+
+// lays the workspace out and points P at its parts
+void carve_workspace(void* ws, int64_t NF, int N, int H, int W, RasterParams& P, int*& binload, int*& order) {
+  float4* bbox = reinterpret_cast<float4*>(ws);
+  float4* rec = bbox + NF;
+  float* fz = reinterpret_cast<float*>(rec + 5 * NF);
+  order = reinterpret_cast<int*>(fz + ((NF + 3) / 4) * 4);
+  binload = order + sched_ints(N, H, W);
+  P.bbox = bbox; P.rec = rec; P.fz = fz; P.order = order; P.total_faces = NF;
+  P.spill = reinterpret_cast<unsigned long long*>(binload + sched_ints(N, H, W) * prep_parts(NF, N));
+}
+
+int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const int64_t* first, int N, int H, int W,
+               int K, void* ws, size_t ws_bytes, hipStream_t st, RasterParams& P) {
+  const size_t need = ur_workspace_bytes(NF, N, H, W, K);
+  if (ws_bytes < need) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+  int* binload = nullptr;
+  int* order = nullptr;
+  carve_workspace(ws, NF, N, H, W, P, binload, order);
+  float4* bbox = const_cast<float4*>(P.bbox);
+  float4* rec = const_cast<float4*>(P.rec);
+  float* fz = const_cast<float*>(P.fz);
+  const int n_bins = N * ((H + 15) / 16) * ((W + 15) / 16);
+  if (hipMemsetAsync(binload, 0, (size_t)n_bins * 4, st) != hipSuccess) return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+  if (NF > 0) {
+    hipLaunchKernelGGL(k_face_prep, dim3((unsigned)((NF + 255) / 256)), dim3(256), 0, st, face_verts, NF,
+                       sqrtf(blur), cull, bbox, rec, fz, first, N, H, W, binload);
+    int rc = check_launch("k_face_prep");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_bin_order, dim3(1), dim3(1024), 0, st, binload, n_bins, order, 1, n_bins);
+  return check_launch("k_bin_order");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// rasterizer backward: one thread per (pixel, k) entry
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void edge_bwd(float px, float py, float ax, float ay, float bx, float by, float g,
+                                         float& gax, float& gay, float& gbx, float& gby) {
+  gax += g * (py - by);
+  gay += g * (bx - px);
+  gbx += -g * (py - ay);
+  gby += g * (px - ax);
+}
+
+__device__ __forceinline__ void seg_bwd(float px, float py, float ax, float ay, float bx, float by, float g, float& gax,
+                                        float& gay, float& gbx, float& gby) {
+  const float bax = bx - ax, bay = by - ay, pax = px - ax, pay = py - ay;
+  const float l2 = bax * bax + bay * bay;
+  if (l2 <= kEps) {
+    gbx += -(2.0f * (px - bx) * g);
+    gby += -(2.0f * (py - by) * g);
+    return;
+  }
+  const float t = (bax * pax + bay * pay) / l2;
+  const float tt = min_s(max_s(t, 0.0f), 1.0f);
+  const float qx = ax + tt * bax, qy = ay + tt * bay;
+  const float basex = g * 2.0f * (px - qx), basey = g * 2.0f * (py - qy);
+  gax += basex * (tt - 1.0f);
+  gay += basey * (tt - 1.0f);
+  gbx += -(basex * tt);
+  gby += -(basey * tt);
+}
+
+// gradient of one fragment wrt its face's nine coordinates, given upstream (gz, gb[3], gd)
+__device__ __forceinline__ void fragment_bwd(const float* __restrict__ fv, float px, float py, bool clip, float gz,
+                                             float gb0, float gb1, float gb2, float gdist, float out[9]) {
+  const float v0x = fv[0], v0y = fv[1], z0 = fv[2], v1x = fv[3], v1y = fv[4], z1 = fv[5], v2x = fv[6], v2y = fv[7],
+              z2 = fv[8];
+  const float denom = ((v2x - v0x) * (v1y - v0y) - (v2y - v0y) * (v1x - v0x)) + kEps;
+  const float e0 = (px - v1x) * (v2y - v1y) - (py - v1y) * (v2x - v1x);
+  const float e1 = (px - v2x) * (v0y - v2y) - (py - v2y) * (v0x - v2x);
+  const float e2 = (px - v0x) * (v1y - v0y) - (py - v0y) * (v1x - v0x);
+  const float w0 = e0 / denom, w1 = e1 / denom, w2 = e2 / denom;
+  float c0 = w0, c1 = w1, c2 = w2, s = 1.0f;
+  bool sum_clamped = false;
+  if (clip) {
+    c0 = max_s(w0, 0.0f); c1 = max_s(w1, 0.0f); c2 = max_s(w2, 0.0f);
+    const float sraw = c0 + c1 + c2;
+    sum_clamped = sraw < 1e-5f;
+    s = max_s(sraw, 1e-5f);
+  }
+  const float g0 = gb0 + gz * z0, g1 = gb1 + gz * z1, g2 = gb2 + gz * z2;
+  float gw0, gw1, gw2;
+  if (clip) {
+    const float gs = sum_clamped ? 0.0f : -(g0 * c0 + g1 * c1 + g2 * c2) / (s * s);
+    gw0 = (w0 > 0.0f) ? (g0 / s + gs) : 0.0f;
+    gw1 = (w1 > 0.0f) ? (g1 / s + gs) : 0.0f;
+    gw2 = (w2 > 0.0f) ? (g2 / s + gs) : 0.0f;
+  } else {
+    gw0 = g0; gw1 = g1; gw2 = g2;
+  }
+  const float ge0 = gw0 / denom, ge1 = gw1 / denom, ge2 = gw2 / denom;
+  const float gden = -(gw0 * w0 + gw1 * w1 + gw2 * w2) / denom;
+  float a0x = 0, a0y = 0, a1x = 0, a1y = 0, a2x = 0, a2y = 0;
+  edge_bwd(px, py, v1x, v1y, v2x, v2y, ge0, a1x, a1y, a2x, a2y);
+  edge_bwd(px, py, v2x, v2y, v0x, v0y, ge1, a2x, a2y, a0x, a0y);
+  edge_bwd(px, py, v0x, v0y, v1x, v1y, ge2, a0x, a0y, a1x, a1y);
+  // denom = edge(v2; v0, v1) + eps : v2 plays the role of the point
+  edge_bwd(v2x, v2y, v0x, v0y, v1x, v1y, gden, a0x, a0y, a1x, a1y);
+  a2x += gden * (v1y - v0y);
+  a2y += -gden * (v1x - v0x);
+  const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+  const float gd = inside ? -gdist : gdist;
+  const float l01 = (v1x - v0x) * (v1x - v0x) + (v1y - v0y) * (v1y - v0y);
+  const float l02 = (v2x - v0x) * (v2x - v0x) + (v2y - v0y) * (v2y - v0y);
+  const float l12 = (v2x - v1x) * (v2x - v1x) + (v2y - v1y) * (v2y - v1y);
+  const float d01 = seg_dist(px, py, v0x, v0y, v1x, v1y, v1x - v0x, v1y - v0y, l01, 1.0f / l01);
+  const float d02 = seg_dist(px, py, v0x, v0y, v2x, v2y, v2x - v0x, v2y - v0y, l02, 1.0f / l02);
+  const float d12 = seg_dist(px, py, v1x, v1y, v2x, v2y, v2x - v1x, v2y - v1y, l12, 1.0f / l12);
+  if (d01 <= d02 && d01 <= d12) seg_bwd(px, py, v0x, v0y, v1x, v1y, gd, a0x, a0y, a1x, a1y);
+  else if (d02 <= d01 && d02 <= d12) seg_bwd(px, py, v0x, v0y, v2x, v2y, gd, a0x, a0y, a2x, a2y);
+  else seg_bwd(px, py, v1x, v1y, v2x, v2y, gd, a1x, a1y, a2x, a2y);
+  out[0] = a0x; out[1] = a0y; out[2] = gz * (c0 / s);
+  out[3] = a1x; out[4] = a1y; out[5] = gz * (c1 / s);
+  out[6] = a2x; out[7] = a2y; out[8] = gz * (c2 / s);
+}
+
+__global__ void __launch_bounds__(256) k_raster_bwd(const float* __restrict__ fv, const int32_t* __restrict__ p2f,
+                                                    const float* __restrict__ gz, const float* __restrict__ gb,
+                                                    const float* __restrict__ gd, int N, int H, int W, int K, int clip,
+                                                    float* __restrict__ gfv) {
+  const int64_t total = (int64_t)N * H * W * K;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int fid = p2f[e];
+    if (fid < 0) continue;
+    const int64_t pix = e / K;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
+    const float ugz = gz ? gz[e] : 0.0f, ugd = gd ? gd[e] : 0.0f;
+    const float ub0 = gb ? gb[e * 3 + 0] : 0.0f, ub1 = gb ? gb[e * 3 + 1] : 0.0f, ub2 = gb ? gb[e * 3 + 2] : 0.0f;
+    float g[9];
+    fragment_bwd(fv + (int64_t)fid * 9, px, py, clip != 0, ugz, ub0, ub1, ub2, ugd, g);
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      if (g[i] != 0.0f) atomicAdd(gfv + (int64_t)fid * 9 + i, g[i]);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// fused backward of the layered render: grad_image -> grad_face_verts (xy only: the layered blend never reads zbuf),
+// grad_maps.  Same decomposition as the forward: workgroup = 16x16 bin, wave = 8x8 tile, lane = pixel.
+//
+// With occ_k = prod_{j<k}(1-a_j), behind_k = colour composited from the layers behind k, dotted with the RGB
+// cotangent g, and trans_k = prod_{j>k}(1-a_j):
+//     dL/dcolour_k = occ_k a_k g                          -> texture scatter + uv -> barycentrics -> vertex xy
+//     dL/da_k      = occ_k (c_k.g - behind_k) + g_A occ_k trans_k            -> signed distance -> vertex xy
+// Step (a): each pixel sweeps its list back to front using (occ, alpha, colour) the forward saved per layer -- a
+// few flops per layer, no geometry -- and leaves (dL/dalpha_k, occ_k a_k) in a scratch array.  Step (b): the
+// expensive part (re-evaluating the face at the pixel, bilinear footprint, chain rule to the vertices) is done per
+// (pixel, layer) ITEM, the tile's items dealt out evenly over the 64 lanes, so lanes stay busy whatever the depth
+// distribution over pixels is.
+//
+// Scatter: instead of one global float atomic per (pixel, layer, component) -- 64 lanes hitting 64 different faces /
+// texture rows, the slowest shape for the memory-side atomic units (~16 G atomics/s measured) -- the workgroup first
+// sums in two small LDS tables keyed by face index / texel index, claimed with an LDS compare-and-swap on a tag; a
+// key whose slot is taken by another key falls back to the global atomic.  One flush per workgroup at the end.
+// The tables hold DOUBLES: gfx950's LDS executes ds_add_f64 at full rate (~10 clk per wave instruction, + ~12 clk per
+// extra lane on the same address) but serialises ds_add_f32 lane by lane (~4 clk per active lane, ~250 clk per wave
+// instruction; tools/micro/lds_atomic*.hip) -- f64 sums are 5x faster here and more accurate.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kFaceSlots = 512;  // x 6 sums
+constexpr int kTexSlots = 256;   // x 3 sums ; slot = 16x16 torus over (texel row, texel column)
+
+__device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, float px, float py, bool clip, float g0,
+                                              float g1, float g2, float o[6]) {
+  // every quotient below is the correctly rounded one (div_by with RN reciprocals): same bits as plain divisions
+  const float w0 = ev.w0, w1 = ev.w1, w2 = ev.w2;
+  float gw0 = g0, gw1 = g1, gw2 = g2;
+  if (clip) {
+    const float c0 = max_s(w0, 0.0f), c1 = max_s(w1, 0.0f), c2 = max_s(w2, 0.0f);
+    const float sraw = c0 + c1 + c2;
+    const float s = max_s(sraw, 1e-5f);
+    const float is = 1.0f / s;
+    const float gs = (sraw < 1e-5f) ? 0.0f : -(g0 * c0 + g1 * c1 + g2 * c2) / (s * s);
+    gw0 = (w0 > 0.0f) ? (div_by(g0, s, is) + gs) : 0.0f;
+    gw1 = (w1 > 0.0f) ? (div_by(g1, s, is) + gs) : 0.0f;
+    gw2 = (w2 > 0.0f) ? (div_by(g2, s, is) + gs) : 0.0f;
+  }
+  const float ge0 = div_by(gw0, f.denom, f.idenom), ge1 = div_by(gw1, f.denom, f.idenom),
+              ge2 = div_by(gw2, f.denom, f.idenom);
+  const float gden = div_by(-(gw0 * w0 + gw1 * w1 + gw2 * w2), f.denom, f.idenom);
+  float a0x = 0, a0y = 0, a1x = 0, a1y = 0, a2x = 0, a2y = 0;
+  edge_bwd(px, py, f.v1x, f.v1y, f.v2x, f.v2y, ge0, a1x, a1y, a2x, a2y);
+  edge_bwd(px, py, f.v2x, f.v2y, f.v0x, f.v0y, ge1, a2x, a2y, a0x, a0y);
+  edge_bwd(px, py, f.v0x, f.v0y, f.v1x, f.v1y, ge2, a0x, a0y, a1x, a1y);
+  edge_bwd(f.v2x, f.v2y, f.v0x, f.v0y, f.v1x, f.v1y, gden, a0x, a0y, a1x, a1y);
+  a2x += gden * (f.v1y - f.v0y);
+  a2y += -gden * (f.v1x - f.v0x);
+  o[0] += a0x; o[1] += a0y; o[2] += a1x; o[3] += a1y; o[4] += a2x; o[5] += a2y;
+}
+
+// claim-or-match a slot of an LDS table; true when `key` owns slot h
+__device__ __forceinline__ bool lds_claim(int* tags, int h, int key) {
+  const int old = atomicCAS(&tags[h], -1, key);
+  return old == -1 || old == key;
+}
+
+__global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
+  __shared__ int s_ftag[kFaceSlots];
+  __shared__ double s_fval[kFaceSlots * 6];
+  __shared__ int s_ttag[kTexSlots];
+  __shared__ double s_tval[kTexSlots * 3];
+  __shared__ int s_pre_all[4 * 136];  // per wave: 64 compacted pixels, then their 65 + pad first-item indices
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = P.H, W = P.W, K = P.K;
+  // same workgroup schedule and pixel ownership as the forward: heaviest bins first; wave w holds every second
+  // column / row of the bin from (w & 1, w >> 1)
+  const int item = P.order[blockIdx.x];
+  const int n = item / (P.nbx * P.nby);
+  const int b = item - n * (P.nbx * P.nby);
+  const int by = b / P.nbx, bx = b - by * P.nbx;
+  const int tx0 = bx * 16 + (wave & 1), ty0 = by * 16 + (wave >> 1);
+  const bool tile_live = (tx0 < W) && (ty0 < H);
+  const int x = tx0 + 2 * (lane & 7), y = ty0 + 2 * (lane >> 3);
+  const bool live = (x < W) && (y < H);
+  const int64_t tile_id = (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
+  const int32_t* lay_tile = P.layers + (tile_live ? tile_id : 0) * (int64_t)K * 6 * 64;  // [K][6][64]
+  const int32_t* lay = lay_tile + lane;
+  float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 2 * 64;         // [K][2][64]
+  float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
+
+  // this pixel's layer count (left by the forward)
+  const int m = (tile_live && live) ? P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] : 0;
+  const int maxm = __builtin_amdgcn_readfirstlane(wave_max(m));
+  if (!__syncthreads_or(maxm > 0)) return;  // nothing rendered in this bin
+  for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
+  for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0;
+  for (int i = tid; i < kTexSlots; i += 256) s_ttag[i] = -1;
+  for (int i = tid; i < kTexSlots * 3; i += 256) s_tval[i] = 0.0;
+  __syncthreads();
+
+  if (maxm > 0) {
+    const int64_t hw = (int64_t)H * W;
+    float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+    if (live) {
+      const float* gi = P.gimage + (int64_t)n * 4 * hw + (int64_t)y * W + x;
+      g0 = gi[0]; g1 = gi[hw]; g2 = gi[2 * hw]; g3 = gi[3 * hw];
+    }
+    // ---- (a) per pixel, back to front, from what the forward saved per layer (transmittance in front, alpha,
+    //      colour): dL/dalpha_k and the colour weight occ_k a_k.  Two layers' loads are issued together.
+    {
+      float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+      float trans = 1.0f;
+      auto sweep = [&](int k, float occ, float a, float cr, float cgc, float cb) {
+        const float cg = g0 * cr + g1 * cgc + g2 * cb;
+        float* sc = scr_tile + (int64_t)k * 2 * 64 + lane;
+        sc[0] = occ * (cg - behind) + g3 * occ * trans;
+        sc[64] = occ * a;
+        behind = a * cg + (1.0f - a) * behind;
+        trans = trans * (1.0f - a);
+      };
+      // four layers' loads are issued together (the records of different layers are independent; only the sweep
+      // itself runs back to front)
+      for (int kb = maxm - 1; kb >= 0; kb -= 4) {
+        float o[4], a[4], cr[4], cg[4], cb[4];
+        bool h[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = kb - u;
+          h[u] = k >= 0 && k < m;
+          const int32_t* l = lay + (int64_t)(k < 0 ? 0 : k) * 6 * 64;
+          o[u] = a[u] = cr[u] = cg[u] = cb[u] = 0.0f;
+          if (h[u]) {
+            o[u] = __int_as_float(l[64]); a[u] = __int_as_float(l[128]); cr[u] = __int_as_float(l[192]);
+            cg[u] = __int_as_float(l[256]); cb[u] = __int_as_float(l[320]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (h[u]) sweep(kb - u, o[u], a[u], cr[u], cg[u], cb[u]);
+      }
+    }
+    // ---- (b) the tile's (pixel, layer) items dealt out evenly over the lanes: geometry is re-evaluated once per
+    //      item, gradients go to the LDS tables
+    const int incl = wave_scan_add(m);
+    const int pre = incl - m;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    // Lane L takes the items [L nb, (L+1) nb) of the tile's pixel-major item list, nb = batches: in any one batch the
+    // 64 lanes then sit in 64 different neighbourhoods of the tile, so few of them meet on the same face / texel --
+    // an LDS atomic costs ~12 clocks per extra lane on its address.  The pixels that have layers are compacted into
+    // (pixel, count) / first-item arrays; a lane finds its first item by binary search and then just walks on.
+    int* s_own = s_pre_all + wave * 136;   // 64 entries: pixel | count << 8
+    int* s_opre = s_own + 64;              // 65 entries: first item of the r-th pixel with layers, then sentinels
+    const unsigned long long om = __ballot(m > 0);
+    const int nown = __popcll(om);
+    if (m > 0) {
+      const int rank = __popcll(om & ((1ull << lane) - 1ull));
+      s_own[rank] = lane | (m << 8);
+      s_opre[rank] = pre;
+    }
+    if (lane >= nown) s_opre[lane] = 0x7fffffff;
+    if (lane == 0) s_opre[64] = 0x7fffffff;
+    const int nbatch = (total + 63) >> 6;
+    const int item0 = lane * nbatch;
+    int rr = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1)
+      if (s_opre[rr + step] <= item0) rr += step;
+    int k = item0 - s_opre[rr];
+    int ow = s_own[rr];
+    const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+    const bool clip = P.clip != 0;
+    for (int bi = 0; bi < nbatch; ++bi, ++k) {
+      if (k >= (ow >> 8)) {  // on to the next pixel that has layers
+        rr = min(rr + 1, 63);
+        ow = s_own[rr];
+        k = 0;
+      }
+      const int item = item0 + bi;
+      int l = ow & 255;
+      if (item >= total) l = lane;
+      // cotangent of the owner pixel (all lanes take part in the shuffles)
+      const float q0 = __shfl(g0, l, 64), q1 = __shfl(g1, l, 64), q2 = __shfl(g2, l, 64);
+      if (item >= total) continue;
+      const int32_t* le = lay_tile + (int64_t)k * 6 * 64 + l;
+      const int fid = le[0];
+      const float a = __int_as_float(le[128]);
+      const float ga = scr_tile[(int64_t)k * 2 * 64 + l], wgt = scr_tile[(int64_t)k * 2 * 64 + 64 + l];
+      const float px = pix_to_ndc(W - 1 - (tx0 + 2 * (l & 7)), W, H), py = pix_to_ndc(H - 1 - (ty0 + 2 * (l >> 3)), H, W);
+      const Face fc = load_face(P.rec, fid);
+      const float* fup = face_uv_row(P, n, fid);
+      const float fu[6] = {fup[0], fup[1], fup[2], fup[3], fup[4], fup[5]};  // in flight with the record
+      Eval ev;
+      eval_face(fc, px, py, P.blur, clip, ev);
+      const float gd = ga * layer_dalpha(ev.sd, a, true, P.sigma, P.mode);
+      float o[6] = {0, 0, 0, 0, 0, 0};
+      if (wgt != 0.0f) {
+        const float u = (ev.c0 * fu[0] + ev.c1 * fu[2]) + ev.c2 * fu[4];
+        const float v = (ev.c0 * fu[1] + ev.c1 * fu[3]) + ev.c2 * fu[5];
+        const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+        int onw, one, osw, ose;
+        bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
+        float gc[3] = {wgt * q0, wgt * q1, wgt * q2};
+        if (P.use_amb) { gc[0] *= P.amb[0]; gc[1] *= P.amb[1]; gc[2] *= P.amb[2]; }
+        if (P.gfv) {
+          float gix = 0.0f, giy = 0.0f;
+          const float y1 = (float)(bl.y0 + 1), x1 = (float)(bl.x0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float t0 = map[onw + ch], t1 = one >= 0 ? map[one + ch] : 0.0f;
+            const float t2 = osw >= 0 ? map[osw + ch] : 0.0f, t3 = ose >= 0 ? map[ose + ch] : 0.0f;
+            const float g = gc[ch];
+            gix -= t0 * (y1 - bl.iy) * g; giy -= t0 * (x1 - bl.ix) * g;
+            gix += t1 * (y1 - bl.iy) * g; giy -= t1 * (bl.ix - x0) * g;
+            gix -= t2 * (bl.iy - y0) * g; giy += t2 * (x1 - bl.ix) * g;
+            gix += t3 * (bl.iy - y0) * g; giy += t3 * (bl.ix - x0) * g;
+          }
+          const float gu = gix * bl.mx * 2.0f, gv = giy * bl.my * 2.0f;
+          const float gb0 = gu * fu[0] + gv * fu[1], gb1 = gu * fu[2] + gv * fu[3], gb2 = gu * fu[4] + gv * fu[5];
+          bary_path_bwd(fc, ev, px, py, clip, gb0, gb1, gb2, o);
+        }
+        if (gmap) {
+          const int offs[4] = {onw, one, osw, ose};
+          const float wts[4] = {bl.wnw, bl.wne, bl.wsw, bl.wse};
+          // texel (row, column) straight from the footprint: flipped rows Ht-1-y0 / Ht-2-y0, columns x0 / x0+1
+          const int r0 = P.Ht - 1 - bl.y0, c0 = bl.x0;
+          int hs[4], tx[4];
+          bool own[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int trow = r0 - (q >> 1), tcol = c0 + (q & 1);
+            tx[q] = trow * P.Wt + tcol;
+            hs[q] = ((trow & 15) << 4) | (tcol & 15);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) own[q] = (offs[q] >= 0) && lds_claim(s_ttag, hs[q], tx[q]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (offs[q] < 0) continue;
+            if (own[q]) {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) atomicAdd(&s_tval[hs[q] * 3 + ch], (double)(gc[ch] * wts[q]));
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) atomicAdd(gmap + offs[q] + ch, gc[ch] * wts[q]);
+            }
+          }
+        }
+      }
+      if (P.gfv && gd != 0.0f) {
+        // d(signed dist)/d(ends of the nearest edge); first minimal edge wins ties
+        const float gs = ev.inside ? -gd : gd;
+        if (ev.d01 <= ev.d02 && ev.d01 <= ev.d12)
+          seg_bwd(px, py, fc.v0x, fc.v0y, fc.v1x, fc.v1y, gs, o[0], o[1], o[2], o[3]);
+        else if (ev.d02 <= ev.d01 && ev.d02 <= ev.d12)
+          seg_bwd(px, py, fc.v0x, fc.v0y, fc.v2x, fc.v2y, gs, o[0], o[1], o[4], o[5]);
+        else
+          seg_bwd(px, py, fc.v1x, fc.v1y, fc.v2x, fc.v2y, gs, o[2], o[3], o[4], o[5]);
+      }
+      if (P.gfv && (wgt != 0.0f || gd != 0.0f)) {
+        const int h = fid & (kFaceSlots - 1);
+        if (lds_claim(s_ftag, h, fid)) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            if (o[i] != 0.0f) atomicAdd(&s_fval[h * 6 + i], (double)o[i]);
+        } else {
+          float* gf = P.gfv + (int64_t)fid * 9;
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            if (o[i] != 0.0f) atomicAdd(gf + (i >> 1) * 3 + (i & 1), o[i]);
+        }
+      }
+    }
+  }
+
+  __syncthreads();
+  if (P.gfv)
+    for (int i = tid; i < kFaceSlots * 6; i += 256) {
+      const int slot = i / 6, c = i - slot * 6;
+      const int tag = s_ftag[slot];
+      const float v = (float)s_fval[i];
+      if (tag >= 0 && v != 0.0f) atomicAdd(P.gfv + (int64_t)tag * 9 + (c >> 1) * 3 + (c & 1), v);
+    }
+  if (gmap)
+    for (int i = tid; i < kTexSlots * 3; i += 256) {
+      const int slot = i / 3, c = i - slot * 3;
+      const int tag = s_ttag[slot];
+      const float v = (float)s_tval[i];
+      if (tag >= 0 && v != 0.0f) atomicAdd(gmap + (int64_t)tag * 3 + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// shading + layered blend (unfused from the rasterizer: consumes fragments).  One thread per pixel.
+// ------------------------------------------------------------------------------------------------------------------
+struct ShadeParams {
+  const int32_t* p2f;
+  const float* bary;
+  const float* dists;
+  const float* maps;
+  const float* fuv;
+  const int64_t* first;
+  int fuv_shared;
+  int N, H, W, K, Ht, Wt;
+  float sigma;
+  float bg[3];
+  float amb[3];
+  int use_amb;
+  int mode;
+  // forward
+  float* image;
+  // backward
+  const float* gimage;
+  float* gmaps;
+  float* gbary;
+  float* gdists;
+};
+
+__device__ __forceinline__ void frag_uv(const ShadeParams& P, int n, int fid, int64_t e, float& u, float& v,
+                                        const float*& fu) {
+  const int64_t fl = P.fuv_shared ? (int64_t)fid - P.first[n] : (int64_t)fid;
+  fu = P.fuv + fl * 6;
+  const float b0 = P.bary[e * 3 + 0], b1 = P.bary[e * 3 + 1], b2 = P.bary[e * 3 + 2];
+  u = (b0 * fu[0] + b1 * fu[2]) + b2 * fu[4];
+  v = (b0 * fu[1] + b1 * fu[3]) + b2 * fu[5];
+}
+
+__global__ void __launch_bounds__(256) k_shade_fwd(const ShadeParams P) {
+  const int64_t npix = (int64_t)P.N * P.H * P.W;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int64_t hw = (int64_t)P.H * P.W;
+  const int n = (int)(pix / hw);
+  const int64_t p = pix - (int64_t)n * hw;
+  const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+  float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = pix * P.K + k;
+    const int fid = P.p2f[e];
+    const bool valid = fid >= 0;
+    const float a = layer_alpha(P.dists[e], valid, P.sigma, P.mode);
+    float u = 0.0f, v = 0.0f;
+    const float* fu;
+    if (valid) frag_uv(P, n, fid, e, u, v, fu);
+    const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+    float cr, cg, cb;
+    sample_rgb(map, bl, P.Ht, P.Wt, cr, cg, cb);
+    if (P.use_amb) { cr *= P.amb[0]; cg *= P.amb[1]; cb *= P.amb[2]; }
+    r += occ * a * cr; g += occ * a * cg; b += occ * a * cb;
+    occ = occ * (1.0f - a);
+  }
+  float* img = P.image + (int64_t)n * 4 * hw + p;
+  img[0] = r + occ * 1.0f * P.bg[0];
+  img[hw] = g + occ * 1.0f * P.bg[1];
+  img[2 * hw] = b + occ * 1.0f * P.bg[2];
+  img[3 * hw] = 1.0f - occ;
+}
+
+// backward: occ_k kept in LDS ([k][thread], conflict free), then a back-to-front sweep
+__global__ void __launch_bounds__(64) k_shade_bwd(const ShadeParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_occ = reinterpret_cast<float*>(smem);  // K * 64 floats
+  const int64_t npix = (int64_t)P.N * P.H * P.W;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int t = threadIdx.x;
+  const int64_t hw = (int64_t)P.H * P.W;
+  const int n = (int)(pix / hw);
+  const int64_t p = pix - (int64_t)n * hw;
+  const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+  float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
+  const float* gi = P.gimage + (int64_t)n * 4 * hw + p;
+  const float g0 = gi[0], g1 = gi[hw], g2 = gi[2 * hw], g3 = gi[3 * hw];
+  float occ = 1.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = pix * P.K + k;
+    s_occ[k * 64 + t] = occ;
+    occ = occ * (1.0f - layer_alpha(P.dists[e], P.p2f[e] >= 0, P.sigma, P.mode));
+  }
+  float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+  float trans = 1.0f;
+  for (int k = P.K - 1; k >= 0; --k) {
+    const int64_t e = pix * P.K + k;
+    const int fid = P.p2f[e];
+    const bool valid = fid >= 0;
+    const float d = P.dists[e];
+    const float a = layer_alpha(d, valid, P.sigma, P.mode);
+    const float ok = s_occ[k * 64 + t];
+    float u = 0.0f, v = 0.0f;
+    const float* fu = nullptr;
+    if (valid) frag_uv(P, n, fid, e, u, v, fu);
+    const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
+    int onw, one, osw, ose;
+    bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
+    float tex[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      tex[0][c] = map[onw + c];
+      tex[1][c] = one >= 0 ? map[one + c] : 0.0f;
+      tex[2][c] = osw >= 0 ? map[osw + c] : 0.0f;
+      tex[3][c] = ose >= 0 ? map[ose + c] : 0.0f;
+    }
+    float col[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.0f;
+      acc += tex[0][c] * bl.wnw; acc += tex[1][c] * bl.wne; acc += tex[2][c] * bl.wsw; acc += tex[3][c] * bl.wse;
+      col[c] = P.use_amb ? acc * P.amb[c] : acc;
+    }
+    const float cg = g0 * col[0] + g1 * col[1] + g2 * col[2];
+    const float ga = ok * (cg - behind) + g3 * ok * trans;
+    P.gdists[e] = ga * layer_dalpha(d, a, valid, P.sigma, P.mode);
+    // d loss / d texel colour (before ambient): occ_k * alpha_k * g * ambient
+    const float wgt = ok * a;
+    float gc[3] = {wgt * g0, wgt * g1, wgt * g2};
+    if (P.use_amb) { gc[0] *= P.amb[0]; gc[1] *= P.amb[1]; gc[2] *= P.amb[2]; }
+    float gix = 0.0f, giy = 0.0f;
+    if (wgt != 0.0f) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float g = gc[c];
+        if (gmap) {
+          atomicAdd(gmap + onw + c, g * bl.wnw);
+          if (one >= 0) atomicAdd(gmap + one + c, g * bl.wne);
+          if (osw >= 0) atomicAdd(gmap + osw + c, g * bl.wsw);
+          if (ose >= 0) atomicAdd(gmap + ose + c, g * bl.wse);
+        }
+        const float y1 = (float)(bl.y0 + 1), x1 = (float)(bl.x0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
+        gix -= tex[0][c] * (y1 - bl.iy) * g; giy -= tex[0][c] * (x1 - bl.ix) * g;
+        gix += tex[1][c] * (y1 - bl.iy) * g; giy -= tex[1][c] * (bl.ix - x0) * g;
+        gix -= tex[2][c] * (bl.iy - y0) * g; giy += tex[2][c] * (x1 - bl.ix) * g;
+        gix += tex[3][c] * (bl.iy - y0) * g; giy += tex[3][c] * (bl.ix - x0) * g;
+      }
+    }
+    float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
+    if (valid) {
+      const float gu = gix * bl.mx * 2.0f, gv = giy * bl.my * 2.0f;
+      gb0 = gu * fu[0] + gv * fu[1]; gb1 = gu * fu[2] + gv * fu[3]; gb2 = gu * fu[4] + gv * fu[5];
+    }
+    P.gbary[e * 3 + 0] = gb0; P.gbary[e * 3 + 1] = gb1; P.gbary[e * 3 + 2] = gb2;
+    behind = a * cg + (1.0f - a) * behind;
+    trans = trans * (1.0f - a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// camera projection fused with the face gather, and its backward
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_project_faces(const float* __restrict__ verts, const int64_t* __restrict__ faces,
+                                                       int64_t fstride, const float* __restrict__ R,
+                                                       const float* __restrict__ T,
+                                                       float sx, float sy, int N, int V, int F,
+                                                       float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, f, corner)
+  if (i >= (int64_t)N * F * 3) return;
+  const int n = (int)(i / ((int64_t)F * 3));
+  const int fc = (int)(i - (int64_t)n * F * 3);
+  const int64_t vi = min(max(faces[(int64_t)n * fstride + fc], (int64_t)0), (int64_t)V - 1);  // no wild reads
+  float o[3];
+  project_vertex(verts + ((int64_t)n * V + vi) * 3, R + (int64_t)n * 9, T + (int64_t)n * 3, sx, sy, o);
+  out[i * 3 + 0] = o[0];
+  out[i * 3 + 1] = o[1];
+  out[i * 3 + 2] = o[2];
+}
+
+// One workgroup per mesh: per-corner gradients are first summed per VERTEX in LDS (the projection is linear in the
+// upstream gradient and depends on the vertex only), then every vertex is pushed through the camera once; the R / T
+// sums are reduced in the workgroup.  No global atomics; outputs are plainly stored.
+__global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __restrict__ verts,
+                                                                 const int64_t* __restrict__ faces, int64_t fstride,
+                                                                 const float* __restrict__ R,
+                                                                 const float* __restrict__ T, float sx, float sy,
+                                                                 int V, int F, const float* __restrict__ gfv,
+                                                                 float* __restrict__ gverts, float* __restrict__ gR,
+                                                                 float* __restrict__ gT, int vwin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // f64 sums: the LDS adds doubles at full rate (ds_add_f64) but serialises ds_add_f32 lane by lane (~4 clk/lane).
+  // blockIdx.y selects a window of `vwin` vertices (meshes whose V*24 B exceed the LDS take several workgroups, each
+  // scanning every corner and keeping those of its window; R / T sums then meet in zero-filled outputs by atomics).
+  double* acc = reinterpret_cast<double*>(smem);  // vwin*3, then 16*12 partial sums
+  float* part = reinterpret_cast<float*>(acc + (size_t)vwin * 3);
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int v_lo = blockIdx.y * vwin, v_hi = min(V, v_lo + vwin);
+  for (int i = tid; i < vwin * 3; i += 1024) acc[i] = 0.0;
+  __syncthreads();
+  const int64_t* fc = faces + (int64_t)n * fstride;
+  const float* g = gfv + (int64_t)n * F * 9;
+  for (int c = tid; c < F * 3; c += 1024) {
+    const int vi = (int)fc[c] - v_lo;
+    if (vi < 0 || vi >= v_hi - v_lo) continue;
+    atomicAdd(&acc[vi * 3 + 0], (double)g[c * 3 + 0]);
+    atomicAdd(&acc[vi * 3 + 1], (double)g[c * 3 + 1]);
+    atomicAdd(&acc[vi * 3 + 2], (double)g[c * 3 + 2]);
+  }
+  __syncthreads();
+  const float* r = R + (int64_t)n * 9;
+  const float* t = T + (int64_t)n * 3;
+  float s[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) s[q] = 0.0f;
+  for (int v = v_lo + tid; v < v_hi; v += 1024) {
+    const float* p = verts + ((int64_t)n * V + v) * 3;
+    const int a = (v - v_lo) * 3;
+    const float g0 = (float)acc[a + 0], g1 = (float)acc[a + 1], g2 = (float)acc[a + 2];
+    const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
+    const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
+    const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
+    const float gv[3] = {g0 * sx / vz, g1 * sy / vz, g2 - (g0 * sx * vx + g1 * sy * vy) / (vz * vz)};
+    if (gverts) {
+      float* go = gverts + ((int64_t)n * V + v) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) go[i] = gv[0] * r[i * 3 + 0] + gv[1] * r[i * 3 + 1] + gv[2] * r[i * 3 + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s[i * 3 + j] += p[i] * gv[j];
+    s[9] += gv[0]; s[10] += gv[1]; s[11] += gv[2];
+  }
+  if (!gR && !gT) return;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    const float v = wave_sum(s[q]);
+    if ((tid & 63) == 63) part[(tid >> 6) * 12 + q] = v;
+  }
+  __syncthreads();
+  if (tid < 12) {
+    float v = 0.0f;
+    for (int w = 0; w < 16; ++w) v += part[w * 12 + tid];
+    float* dst = tid < 9 ? (gR ? gR + (int64_t)n * 9 + tid : nullptr) : (gT ? gT + (int64_t)n * 3 + tid - 9 : nullptr);
+    if (dst) {
+      if (gridDim.y == 1) *dst = v; else atomicAdd(dst, v);
+    }
+  }
+}
+
+// div_by() against the hardware's IEEE division on pseudo-random operand pairs spanning the ranges the rasterizer
+// produces (numerators down to 0 and to tiny cancellation residues, denominators from 1e-8 up, both signs)
+__global__ void __launch_bounds__(256) k_selftest_division(unsigned long long n, unsigned seed,
+                                                           unsigned long long* mismatches) {
+  unsigned long long bad = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    const unsigned ua = (unsigned)x, ub = (unsigned)(x >> 32);
+    // exponents: a in 2^[-60, 3), b in 2^[-27, 3); random mantissas and signs; every 64th numerator is 0
+    float a = __uint_as_float((ua & 0x807fffffu) | ((67u + (ua >> 23) % 63u) << 23));
+    const float b = __uint_as_float((ub & 0x807fffffu) | ((100u + (ub >> 23) % 30u) << 23));
+    if ((i & 63) == 0) a = 0.0f;
+    const float want = a / b, got = div_by(a, b, 1.0f / b);
+    if (!(want == got)) ++bad;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// blending of per-fragment colours that the caller computed (lit colours of phong / flat / gouraud shading):
+// kind 0..2 = layered_rgb_blend's three alpha modes (renderer.py:175-202), kind 3 = pytorch3d's softmax_rgb_blend
+// (reached through SoftPhongShaderPlus, renderer.py:205-208).  One thread per pixel, K fragments each.
+// ------------------------------------------------------------------------------------------------------------------
+struct BlendParamsK {
+  const float* colors;   // (N,H,W,K,3)
+  const int32_t* p2f;    // (N,H,W,K)
+  const float* dists;
+  const float* zbuf;     // softmax only
+  int N, H, W, K, kind;
+  float sigma, gamma, znear, zfar;
+  float bg[3];
+  float* image;          // (N,4,H,W)
+  const float* gimage;
+  float* gcolors;
+  float* gdists;
+  float* gzbuf;
+};
+
+constexpr float kSoftEps = 1e-10f;
+
+// sigma == 0 (the viz settings, renderer.py:53): sigmoid(-d/0) is a step; d == 0 would be 0/0, taken as covered
+__device__ __forceinline__ float soft_prob(float d, bool valid, float sigma) {
+  if (!valid) return 0.0f;
+  if (sigma == 0.0f) return d <= 0.0f ? 1.0f : 0.0f;
+  return 1.0f / (1.0f + expf(d / sigma));
+}
+
+__global__ void __launch_bounds__(256) k_blend_fwd(const BlendParamsK P) {
+  const int64_t npix = (int64_t)P.N * P.H * P.W;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int64_t hw = (int64_t)P.H * P.W;
+  const int n = (int)(pix / hw);
+  const int64_t p = pix - (int64_t)n * hw;
+  float* img = P.image + (int64_t)n * 4 * hw + p;
+  const int64_t base = pix * P.K;
+  if (P.kind < 3) {
+    float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+    for (int k = 0; k < P.K; ++k) {
+      const int64_t e = base + k;
+      const float a = layer_alpha(P.dists[e], P.p2f[e] >= 0, P.sigma, P.kind);
+      r += occ * a * P.colors[e * 3 + 0]; g += occ * a * P.colors[e * 3 + 1]; b += occ * a * P.colors[e * 3 + 2];
+      occ = occ * (1.0f - a);
+    }
+    img[0] = r + occ * 1.0f * P.bg[0];
+    img[hw] = g + occ * 1.0f * P.bg[1];
+    img[2 * hw] = b + occ * 1.0f * P.bg[2];
+    img[3 * hw] = 1.0f - occ;
+    return;
+  }
+  const float zden = P.zfar - P.znear;
+  float alpha = 1.0f, zmax = 0.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    alpha *= (1.0f - soft_prob(P.dists[e], valid, P.sigma));
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    zmax = (k == 0) ? zinv : max_s(zmax, zinv);
+  }
+  zmax = max_s(zmax, kSoftEps);
+  const float delta = max_s(expf((kSoftEps - zmax) / P.gamma), kSoftEps);
+  float denom = delta, r = 0.0f, g = 0.0f, b = 0.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    const float w = soft_prob(P.dists[e], valid, P.sigma) * expf((zinv - zmax) / P.gamma);
+    denom += w;
+    r += w * P.colors[e * 3 + 0]; g += w * P.colors[e * 3 + 1]; b += w * P.colors[e * 3 + 2];
+  }
+  img[0] = (r + delta * P.bg[0]) / denom;
+  img[hw] = (g + delta * P.bg[1]) / denom;
+  img[2 * hw] = (b + delta * P.bg[2]) / denom;
+  img[3 * hw] = 1.0f - alpha;
+}
+
+__global__ void __launch_bounds__(256) k_blend_bwd(const BlendParamsK P) {
+  const int64_t npix = (int64_t)P.N * P.H * P.W;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int64_t hw = (int64_t)P.H * P.W;
+  const int n = (int)(pix / hw);
+  const int64_t p = pix - (int64_t)n * hw;
+  const float* gi = P.gimage + (int64_t)n * 4 * hw + p;
+  const float g0 = gi[0], g1 = gi[hw], g2 = gi[2 * hw], g3 = gi[3 * hw];
+  const int64_t base = pix * P.K;
+  if (P.kind < 3) {
+    // transmittance in front of every layer is recomputed front to back on the way (two sweeps, no scratch):
+    // first the total, then back to front dividing out is inexact -- so sweep forward per layer instead: O(K^2)
+    // would be wasteful; keep the forward products in the gradient buffers (gdists as scratch) and read them back
+    float occ = 1.0f;
+    for (int k = 0; k < P.K; ++k) {
+      const int64_t e = base + k;
+      P.gdists[e] = occ;
+      occ = occ * (1.0f - layer_alpha(P.dists[e], P.p2f[e] >= 0, P.sigma, P.kind));
+    }
+    float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+    float trans = 1.0f;
+    for (int k = P.K - 1; k >= 0; --k) {
+      const int64_t e = base + k;
+      const bool valid = P.p2f[e] >= 0;
+      const float d = P.dists[e];
+      const float a = layer_alpha(d, valid, P.sigma, P.kind);
+      const float ok = P.gdists[e];
+      const float c0 = P.colors[e * 3 + 0], c1 = P.colors[e * 3 + 1], c2 = P.colors[e * 3 + 2];
+      const float cg = g0 * c0 + g1 * c1 + g2 * c2;
+      const float ga = ok * (cg - behind) + g3 * ok * trans;
+      P.gdists[e] = ga * layer_dalpha(d, a, valid, P.sigma, P.kind);
+      const float wgt = ok * a;
+      P.gcolors[e * 3 + 0] = wgt * g0; P.gcolors[e * 3 + 1] = wgt * g1; P.gcolors[e * 3 + 2] = wgt * g2;
+      if (P.gzbuf) P.gzbuf[e] = 0.0f;
+      behind = a * cg + (1.0f - a) * behind;
+      trans = trans * (1.0f - a);
+    }
+    return;
+  }
+  // ---- softmax blend: torch autograd's rules for the published formula (max -> first maximal entry, clamp(min)
+  //      passes where the input is >= the bound, prod differentiated exactly also with zero factors)
+  const float zden = P.zfar - P.znear;
+  float zraw = 0.0f;
+  int kmax = 0, zeros = 0, kzero = -1;
+  float prod_nz = 1.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    const float pr = soft_prob(P.dists[e], valid, P.sigma);
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    if (k == 0 || zinv > zraw) { zraw = zinv; kmax = k; }
+    const float f = 1.0f - pr;
+    if (f == 0.0f) { ++zeros; kzero = k; } else prod_nz *= f;
+  }
+  const float zmax = max_s(zraw, kSoftEps);
+  const float delta_raw = expf((kSoftEps - zmax) / P.gamma);
+  const float delta = max_s(delta_raw, kSoftEps);
+  float denom = delta, S0 = delta * P.bg[0], S1 = delta * P.bg[1], S2 = delta * P.bg[2];
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    const float w = soft_prob(P.dists[e], valid, P.sigma) * expf((zinv - zmax) / P.gamma);
+    denom += w;
+    S0 += w * P.colors[e * 3 + 0]; S1 += w * P.colors[e * 3 + 1]; S2 += w * P.colors[e * 3 + 2];
+  }
+  const float rgb_dot = g0 * (S0 / denom) + g1 * (S1 / denom) + g2 * (S2 / denom);
+  float g_zmax = 0.0f;
+  for (int k = 0; k < P.K; ++k) {
+    const int64_t e = base + k;
+    const bool valid = P.p2f[e] >= 0;
+    const float pr = soft_prob(P.dists[e], valid, P.sigma);
+    const float zinv = valid ? (P.zfar - P.zbuf[e]) / zden : 0.0f;
+    const float ex = expf((zinv - zmax) / P.gamma);
+    const float w = pr * ex;
+    const float c0 = P.colors[e * 3 + 0], c1 = P.colors[e * 3 + 1], c2 = P.colors[e * 3 + 2];
+    P.gcolors[e * 3 + 0] = g0 * w / denom; P.gcolors[e * 3 + 1] = g1 * w / denom; P.gcolors[e * 3 + 2] = g2 * w / denom;
+    const float g_w = ((g0 * c0 + g1 * c1 + g2 * c2) - rgb_dot) / denom;
+    float g_prob = g_w * ex;
+    const float g_zinv = g_w * w / P.gamma;
+    g_zmax -= g_w * w / P.gamma;
+    const float others = zeros == 0 ? prod_nz / (1.0f - pr) : ((zeros == 1 && k == kzero) ? prod_nz : 0.0f);
+    g_prob += g3 * others;
+    P.gdists[e] = (valid && P.sigma > 0.0f) ? g_prob * pr * (1.0f - pr) * (-1.0f / P.sigma) : 0.0f;
+    if (P.gzbuf) P.gzbuf[e] = valid ? -g_zinv / zden : 0.0f;
+  }
+  const float g_delta = ((g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2]) - rgb_dot) / denom;
+  if (delta_raw >= kSoftEps) g_zmax -= g_delta * delta_raw / P.gamma;
+  if (P.gzbuf && zraw >= kSoftEps && P.p2f[base + kmax] >= 0) P.gzbuf[base + kmax] += -g_zmax / zden;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// mesh regularisers of the 3D step (unicorn.py:338-343): normal consistency over edges (utils/mesh.py:92-139) and the
+// uniform Laplacian (pytorch3d mesh_laplacian_smoothing(method='uniform')), value AND gradient in one launch.
+// One workgroup per mesh; all meshes share one topology (edge table + vertex adjacency, built once on the host).
+//   edge table row = (v0, v1, a, b): the edge and the third vertex of each of its two faces
+//   normal term    = sum_e 1 - cos(n0, n1), n0 = (v1-v0) x (a-v0), n1 = -((v1-v0) x (b-v0)), cos with norms clamped at 1e-8
+//   laplacian term = sum_i || mean_{j in N(i)} v_j - v_i ||
+// Edge gradients are summed per vertex in an f64 LDS table when V*24 B fit (no global atomics), else float atomics.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ void __launch_bounds__(1024) k_mesh_reg(const float* __restrict__ verts, int V, const int4* __restrict__ quads,
+                                                   int E, const int* __restrict__ nbr_off, const int* __restrict__ nbr_idx,
+                                                   float* __restrict__ nsum, float* __restrict__ lsum,
+                                                   float* __restrict__ gN, float* __restrict__ gL,
+                                                   float* __restrict__ scratch, int lds_acc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* part = reinterpret_cast<float*>(smem);          // 2 x 16 wave partial sums
+  double* acc = reinterpret_cast<double*>(smem + 128);   // V*3 when lds_acc
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* vp = verts + (int64_t)n * V * 3;
+  float* gn = gN ? gN + (int64_t)n * V * 3 : nullptr;
+  float* gl = gL ? gL + (int64_t)n * V * 3 : nullptr;
+  float* u = scratch + (int64_t)n * V * 3;
+  if (gn) {
+    if (lds_acc) for (int i = tid; i < V * 3; i += 1024) acc[i] = 0.0;
+    else for (int i = tid; i < V * 3; i += 1024) gn[i] = 0.0f;
+  }
+  __syncthreads();
+  // ---- normal consistency
+  float nloss = 0.0f;
+  for (int e = tid; e < E; e += 1024) {
+    const int4 q = quads[e];
+    float v0[3], ev[3], pa[3], pb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      v0[c] = vp[q.x * 3 + c];
+      ev[c] = vp[q.y * 3 + c] - v0[c];
+      pa[c] = vp[q.z * 3 + c] - v0[c];
+      pb[c] = vp[q.w * 3 + c] - v0[c];
+    }
+    float n0[3], n1[3];
+    cross3(ev, pa, n0);
+    cross3(pb, ev, n1);  // = -(e x pb)
+    const float l0 = sqrtf(n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]);
+    const float l1 = sqrtf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+    const float m0 = max_s(l0, 1e-8f), m1 = max_s(l1, 1e-8f);
+    const float dot = n0[0] * n1[0] + n0[1] * n1[1] + n0[2] * n1[2];
+    const float cs = dot / (m0 * m1);
+    nloss += 1.0f - cs;
+    if (gn) {
+      // d(1 - cos)/dn0 = -(n1/(m0 m1) - cos n0/m0^2 [if l0 > eps]), likewise n1
+      float g0[3], g1[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        g0[c] = -(n1[c] / (m0 * m1) - (l0 > 1e-8f ? cs * n0[c] / (m0 * m0) : 0.0f));
+        g1[c] = -(n0[c] / (m0 * m1) - (l1 > 1e-8f ? cs * n1[c] / (m1 * m1) : 0.0f));
+      }
+      // n0 = e x pa: d/de = pa x g0, d/dpa = g0 x e ; n1 = pb x e: d/dpb = e x g1, d/de = g1 x pb
+      float ge[3], gpa[3], gpb[3], t[3];
+      cross3(pa, g0, ge);
+      cross3(g1, pb, t);
+      cross3(g0, ev, gpa);
+      cross3(ev, g1, gpb);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        ge[c] += t[c];
+        const float gv0 = -(ge[c] + gpa[c] + gpb[c]);
+        if (lds_acc) {
+          atomicAdd(&acc[q.x * 3 + c], (double)gv0); atomicAdd(&acc[q.y * 3 + c], (double)ge[c]);
+          atomicAdd(&acc[q.z * 3 + c], (double)gpa[c]); atomicAdd(&acc[q.w * 3 + c], (double)gpb[c]);
+        } else {
+          atomicAdd(&gn[q.x * 3 + c], gv0); atomicAdd(&gn[q.y * 3 + c], ge[c]);
+          atomicAdd(&gn[q.z * 3 + c], gpa[c]); atomicAdd(&gn[q.w * 3 + c], gpb[c]);
+        }
+      }
+    }
+  }
+  // ---- uniform Laplacian: pass 1, u_i = Lv_i / ||Lv_i|| parked in scratch
+  float lloss = 0.0f;
+  for (int i = tid; i < V; i += 1024) {
+    const int b = nbr_off[i], e = nbr_off[i + 1];
+    float s[3] = {0.0f, 0.0f, 0.0f};
+    for (int j = b; j < e; ++j) {
+      const int k = nbr_idx[j];
+      s[0] += vp[k * 3 + 0]; s[1] += vp[k * 3 + 1]; s[2] += vp[k * 3 + 2];
+    }
+    const float inv = e > b ? 1.0f / (float)(e - b) : 0.0f;
+    float lv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lv[c] = s[c] * inv - vp[i * 3 + c];
+    const float r = sqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
+    lloss += r;
+    const float ir = r > 0.0f ? 1.0f / r : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u[i * 3 + c] = lv[c] * ir;
+  }
+  // block sums
+  const float wn = wave_sum(nloss), wl = wave_sum(lloss);
+  if ((tid & 63) == 63) { part[tid >> 6] = wn; part[16 + (tid >> 6)] = wl; }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.0f, b = 0.0f;
+    for (int w = 0; w < 16; ++w) { a += part[w]; b += part[16 + w]; }
+    nsum[n] = a;
+    lsum[n] = b;
+  }
+  // ---- pass 2: d/dv_i sum_k ||Lv_k|| = sum_{j in N(i)} u_j / deg_j - u_i  (adjacency is symmetric)
+  if (gl)
+    for (int i = tid; i < V; i += 1024) {
+      float g[3] = {-u[i * 3 + 0], -u[i * 3 + 1], -u[i * 3 + 2]};
+      for (int j = nbr_off[i]; j < nbr_off[i + 1]; ++j) {
+        const int k = nbr_idx[j];
+        const float inv = 1.0f / (float)(nbr_off[k + 1] - nbr_off[k]);
+        g[0] += u[k * 3 + 0] * inv; g[1] += u[k * 3 + 1] * inv; g[2] += u[k * 3 + 2] * inv;
+      }
+      gl[i * 3 + 0] = g[0]; gl[i * 3 + 1] = g[1]; gl[i * 3 + 2] = g[2];
+    }
+  if (gn && lds_acc)
+    for (int i = tid; i < V * 3; i += 1024) gn[i] = (float)acc[i];
+}
+
+int fill_blend_params(BlendParamsK& P, const float* colors, const int32_t* p2f, const float* dists, const float* zbuf,
+                      int N, int H, int W, int K, int kind, float sigma, float gamma, const float* bg, float znear,
+                      float zfar) {
+  if (!colors || !p2f || !dists || !bg) return fail(UR_ERR_INVALID_ARG, "null input pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (kind < 0 || kind > 3) return fail(UR_ERR_INVALID_ARG, "bad blend kind %d", kind);
+  if ((kind == UR_BLEND_CLIP_INSIDE || kind == UR_BLEND_SIGMOID) && !(sigma > 0.0f))
+    return fail(UR_ERR_INVALID_ARG, "sigma must be > 0 for soft blending");
+  if (kind == UR_BLEND_SOFTMAX) {
+    if (!(sigma >= 0.0f)) return fail(UR_ERR_INVALID_ARG, "sigma must be >= 0");
+    if (!zbuf) return fail(UR_ERR_INVALID_ARG, "softmax blend needs zbuf");
+    if (!(gamma > 0.0f) || !(zfar > znear)) return fail(UR_ERR_INVALID_ARG, "softmax blend needs gamma > 0, zfar > znear");
+  }
+  P.colors = colors; P.p2f = p2f; P.dists = dists; P.zbuf = zbuf;
+  P.N = N; P.H = H; P.W = W; P.K = K; P.kind = kind;
+  P.sigma = sigma; P.gamma = gamma; P.znear = znear; P.zfar = zfar;
+  for (int i = 0; i < 3; ++i) P.bg[i] = bg[i];
+  P.image = nullptr; P.gimage = nullptr; P.gcolors = nullptr; P.gdists = nullptr; P.gzbuf = nullptr;
+  return UR_OK;
+}
+
+int fill_shade_params(ShadeParams& P, const int32_t* p2f, const float* bary, const float* dists, const float* maps,
+                      const float* fuv, int fuv_shared, const int64_t* first, int N, int H, int W, int K, int Ht, int Wt,
+                      float sigma, const float* bg, const float* amb, int mode) {
+  if (!p2f || !bary || !dists || !maps || !fuv || !bg) return fail(UR_ERR_INVALID_ARG, "null input pointer");
+  if (fuv_shared && !first) return fail(UR_ERR_INVALID_ARG, "face_uvs_shared needs mesh_first_face");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || Ht <= 0 || Wt <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (mode < 0 || mode > 2) return fail(UR_ERR_INVALID_ARG, "bad blend mode %d", mode);
+  if (mode != UR_BLEND_HARD && !(sigma > 0.0f)) return fail(UR_ERR_INVALID_ARG, "sigma must be > 0 for soft blending");
+  P.p2f = p2f; P.bary = bary; P.dists = dists; P.maps = maps; P.fuv = fuv; P.first = first; P.fuv_shared = fuv_shared;
+  P.N = N; P.H = H; P.W = W; P.K = K; P.Ht = Ht; P.Wt = Wt; P.sigma = sigma; P.mode = mode;
+  for (int i = 0; i < 3; ++i) { P.bg[i] = bg[i]; P.amb[i] = amb ? amb[i] : 1.0f; }
+  P.use_amb = amb && !(amb[0] == 1.0f && amb[1] == 1.0f && amb[2] == 1.0f);
+  P.image = nullptr; P.gimage = nullptr; P.gmaps = nullptr; P.gbary = nullptr; P.gdists = nullptr;
+  return UR_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================================
+// C ABI
+// ====================================================================================================================
+extern "C" {
+
+const char* ur_last_error(void) { return g_err; }
+int ur_abi_version(void) { return 2; }
+
+int ur_profile_begin(int max_launches) {
+  if (max_launches <= 0) return fail(UR_ERR_INVALID_ARG, "max_launches must be > 0");
+  if (g_prof.on.load()) return fail(UR_ERR_INVALID_ARG, "profiling already on");
+  g_prof.ev.assign((size_t)2 * max_launches, nullptr);
+  g_prof.kind.assign((size_t)max_launches, UR_PROFILE_OTHER);
+  for (auto& e : g_prof.ev)
+    if (hipEventCreate(&e) != hipSuccess) return fail(UR_ERR_LAUNCH, "hipEventCreate failed");
+  g_prof.next.store(0);
+  g_prof.on.store(true, std::memory_order_release);
+  return UR_OK;
+}
+
+int ur_profile_end(float* ms, int* kinds, int capacity, int* count) {
+  if (!g_prof.on.load()) return fail(UR_ERR_INVALID_ARG, "profiling is not on");
+  g_prof.on.store(false);
+  const int n = std::min(g_prof.next.load(), (int)g_prof.kind.size());
+  int out = 0;
+  for (int i = 0; i < n; ++i) {
+    float t = 0.0f;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+      continue;
+    if (out < capacity && ms && kinds) { ms[out] = t; kinds[out] = g_prof.kind[i]; }
+    ++out;
+  }
+  for (auto e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.kind.clear();
+  if (count) *count = out < capacity ? out : capacity;
+  return UR_OK;
+}
+
+size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
+  // bbox (16 B) + record (80 B) + nearest depth (4 B) per face, the workgroup schedule, then the spill area of the per-pixel K-lists (only when K exceeds what
+  // LDS holds)
+  const size_t nf = (size_t)(total_faces < 1 ? 1 : total_faces);
+  return nf * 96 + ((nf + 3) / 4) * 16 +
+         (size_t)(1 + prep_parts(total_faces, N)) * sched_ints(N < 0 ? 0 : N, H, W) * 4 +
+         raster_spill_bytes(total_faces, N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
+}
+
+int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                     const float* T, float sx, float sy, int N, int V, int F, float* face_verts, void* stream) {
+  if (!verts || !faces || !R || !T || !face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  const int64_t total = (int64_t)N * F * 3;
+  if (total == 0) return UR_OK;
+  hipLaunchKernelGGL(k_project_faces, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts,
+                     faces, faces_mesh_stride, R, T, sx, sy, N, V, F, face_verts);
+  return check_launch("k_project_faces");
+}
+
+int ur_project_faces_backward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                              const float* T, float sx, float sy, int N, int V, int F, const float* grad_face_verts,
+                              float* grad_verts, float* grad_R, float* grad_T, void* stream) {
+  if (!verts || !faces || !R || !T || !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (N == 0 || F == 0 || (!grad_verts && !grad_R && !grad_T)) return UR_OK;
+  // vertex windows: as few as make a window's f64 sums fit the LDS (one for the meshes of the reference's configs up
+  // to level 4; a level-5 icosphere, 10242 vertices, takes two)
+  const int max_win = (150 * 1024 - 16 * 12 * 4) / 24;
+  const int nwin = (V + max_win - 1) / max_win;
+  const int vwin = (V + nwin - 1) / nwin;
+  const size_t lds = (size_t)vwin * 3 * 8 + 16 * 12 * 4;
+  if (N > 65535 || nwin > 65535) return fail(UR_ERR_INVALID_ARG, "too many meshes / vertices per call");
+  static LdsSlot lds_slot;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_project_faces_bwd_mesh), lds, lds_slot)) return rc;
+  if (nwin > 1) {
+    if (grad_R) (void)hipMemsetAsync(grad_R, 0, (size_t)N * 36, (hipStream_t)stream);
+    if (grad_T) (void)hipMemsetAsync(grad_T, 0, (size_t)N * 12, (hipStream_t)stream);
+  }
+  hipLaunchKernelGGL(k_project_faces_bwd_mesh, dim3((unsigned)N, (unsigned)nwin), dim3(1024), lds, (hipStream_t)stream,
+                     verts, faces, faces_mesh_stride, R, T, sx, sy, V, F, grad_face_verts, grad_verts, grad_R, grad_T,
+                     vwin);
+  return check_launch("k_project_faces_bwd_mesh");
+}
+
+int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
+                        int64_t total_faces, int H, int W, float blur_radius, int K, int perspective_correct,
+                        int clip_barycentric_coords, int cull_backfaces, int32_t* pix_to_face, float* zbuf,
+                        float* bary, float* dists, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!face_verts || !mesh_first_face || !mesh_num_faces || !pix_to_face)
+    return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || total_faces < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (!(blur_radius >= 0.0f)) return fail(UR_ERR_INVALID_ARG, "blur_radius must be >= 0");
+  if (perspective_correct) return fail(UR_ERR_UNSUPPORTED, "perspective_correct=True is not supported");
+  if (total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "more than 2^31-1 faces");
+  if (N == 0) return UR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  RasterParams P{};
+  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, mesh_first_face, N, H, W, K, workspace,
+                      workspace_bytes, st, P);
+  if (rc) return rc;
+  P.first = mesh_first_face; P.nfaces = mesh_num_faces;
+  P.N = N; P.H = H; P.W = W; P.K = K; P.blur = blur_radius; P.clip = clip_barycentric_coords;
+  P.p2f = pix_to_face; P.zbuf = zbuf; P.bary = bary; P.dists = dists;
+  return launch_raster<0>(P, st);
+}
+
+int ur_tile_faces(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,
+                  int64_t total_faces, int H, int W, float blur_radius, int cull_backfaces, int cap, int32_t* counts,
+                  int32_t* lists, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!face_verts || !mesh_first_face || !mesh_num_faces || !counts || !lists)
+    return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || cap <= 0 || total_faces < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (N == 0) return UR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  RasterParams P{};
+  int rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, mesh_first_face, N, H, W, 1, workspace,
+                      workspace_bytes, st, P);
+  if (rc) return rc;
+  P.first = mesh_first_face; P.nfaces = mesh_num_faces;
+  P.N = N; P.H = H; P.W = W; P.K = 1; P.blur = blur_radius; P.clip = 0;
+  P.tl_counts = counts; P.tl_lists = lists; P.tl_cap = cap;
+  return launch_raster<1>(P, st);
+}
+
+int ur_rasterize_meshes_backward(const float* face_verts, const int32_t* pix_to_face, const float* grad_zbuf,
+                                 const float* grad_bary, const float* grad_dists, int N, int64_t total_faces, int H,
+                                 int W, int K, int perspective_correct, int clip_barycentric_coords,
+                                 float* grad_face_verts, void* stream) {
+  if (!face_verts || !pix_to_face || !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || total_faces < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (perspective_correct) return fail(UR_ERR_UNSUPPORTED, "perspective_correct=True is not supported");
+  const int64_t total = (int64_t)N * H * W * K;
+  if (total == 0 || (!grad_zbuf && !grad_bary && !grad_dists)) return UR_OK;
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(k_raster_bwd, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, N, H, W, K,
+                     clip_barycentric_coords, grad_face_verts);
+  return check_launch("k_raster_bwd");
+}
+
+int ur_shade_blend(const int32_t* pix_to_face, const float* bary, const float* dists, const float* maps,
+                   const float* face_uvs, int face_uvs_shared, const int64_t* mesh_first_face, int N, int H, int W,
+                   int K, int Ht, int Wt, float sigma, const float* background, const float* ambient, int mode,
+                   float* image, void* stream) {
+  ShadeParams P;
+  int rc = fill_shade_params(P, pix_to_face, bary, dists, maps, face_uvs, face_uvs_shared, mesh_first_face, N, H, W, K,
+                             Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (!image) return fail(UR_ERR_INVALID_ARG, "null image");
+  P.image = image;
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  hipLaunchKernelGGL(k_shade_fwd, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+  return check_launch("k_shade_fwd");
+}
+
+int ur_shade_blend_backward(const float* grad_image, const int32_t* pix_to_face, const float* bary,
+                            const float* dists, const float* maps, const float* face_uvs, int face_uvs_shared,
+                            const int64_t* mesh_first_face, int N, int H, int W, int K, int Ht, int Wt, float sigma,
+                            const float* background, const float* ambient, int mode, float* grad_maps,
+                            float* grad_bary, float* grad_dists, void* stream) {
+  ShadeParams P;
+  int rc = fill_shade_params(P, pix_to_face, bary, dists, maps, face_uvs, face_uvs_shared, mesh_first_face, N, H, W, K,
+                             Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (!grad_image || !grad_bary || !grad_dists) return fail(UR_ERR_INVALID_ARG, "null gradient pointer");
+  P.gimage = grad_image; P.gmaps = grad_maps; P.gbary = grad_bary; P.gdists = grad_dists;
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  const size_t lds = (size_t)K * 64 * 4;
+  if (lds > 150 * 1024) return fail(UR_ERR_UNSUPPORTED, "faces_per_pixel=%d too large for the blend backward", K);
+  static LdsSlot lds_slot;
+  if (int rc2 = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_shade_bwd), lds, lds_slot)) return rc2;
+  hipLaunchKernelGGL(k_shade_bwd, dim3((unsigned)((npix + 63) / 64)), dim3(64), lds, (hipStream_t)stream, P);
+  return check_launch("k_shade_bwd");
+}
+
+int ur_mesh_regularizers(const float* verts, int N, int V, const int32_t* edge_quads, int E, const int32_t* nbr_offsets,
+                         const int32_t* nbr_index, float* normal_sum, float* laplacian_sum, float* grad_normal,
+                         float* grad_laplacian, float* scratch, void* stream) {
+  if (!verts || !edge_quads || !nbr_offsets || !nbr_index || !normal_sum || !laplacian_sum || !scratch)
+    return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || V <= 0 || E < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (reinterpret_cast<uintptr_t>(edge_quads) & 15) return fail(UR_ERR_INVALID_ARG, "edge table must be 16-byte aligned");
+  if (N == 0) return UR_OK;
+  const size_t lds_full = 128 + (size_t)V * 3 * 8;
+  const int lds_acc = lds_full <= 150 * 1024;
+  const size_t lds = lds_acc ? lds_full : 128;
+  static LdsSlot lds_slot;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_mesh_reg), lds, lds_slot)) return rc;
+  hipLaunchKernelGGL(k_mesh_reg, dim3((unsigned)N), dim3(1024), lds, (hipStream_t)stream, verts, V,
+                     reinterpret_cast<const int4*>(edge_quads), E, nbr_offsets, nbr_index, normal_sum, laplacian_sum,
+                     grad_normal, grad_laplacian, scratch, lds_acc);
+  return check_launch("k_mesh_reg");
+}
+
+int ur_blend_colors(const float* colors, const int32_t* pix_to_face, const float* dists, const float* zbuf, int N,
+                    int H, int W, int K, int kind, float sigma, float gamma, const float* background, float znear,
+                    float zfar, float* image, void* stream) {
+  BlendParamsK P{};
+  int rc = fill_blend_params(P, colors, pix_to_face, dists, zbuf, N, H, W, K, kind, sigma, gamma, background, znear,
+                             zfar);
+  if (rc) return rc;
+  if (!image) return fail(UR_ERR_INVALID_ARG, "null output pointer");
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  P.image = image;
+  hipLaunchKernelGGL(k_blend_fwd, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+  return check_launch("k_blend_fwd");
+}
+
+int ur_blend_colors_backward(const float* grad_image, const float* colors, const int32_t* pix_to_face,
+                             const float* dists, const float* zbuf, int N, int H, int W, int K, int kind, float sigma,
+                             float gamma, const float* background, float znear, float zfar, float* grad_colors,
+                             float* grad_dists, float* grad_zbuf, void* stream) {
+  BlendParamsK P{};
+  int rc = fill_blend_params(P, colors, pix_to_face, dists, zbuf, N, H, W, K, kind, sigma, gamma, background, znear,
+                             zfar);
+  if (rc) return rc;
+  if (!grad_image || !grad_colors || !grad_dists) return fail(UR_ERR_INVALID_ARG, "null gradient pointer");
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  P.gimage = grad_image; P.gcolors = grad_colors; P.gdists = grad_dists; P.gzbuf = grad_zbuf;
+  hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+  return check_launch("k_blend_bwd");
+}
+
+int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* stream) {
+  if (!mismatches) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  hipLaunchKernelGGL(k_selftest_division, dim3(2048), dim3(256), 0, (hipStream_t)stream, (unsigned long long)n, seed,
+                     reinterpret_cast<unsigned long long*>(mismatches));
+  return check_launch("k_selftest_division");
+}
+
+size_t ur_backward_scratch_bytes(int N, int H, int W, int K) {
+  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * (size_t)K * 64 * 2 * 4;
+}
+
+size_t ur_layers_elems(int N, int H, int W, int K) {
+  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * ((size_t)K * 64 * 6 + 64);
+}
+
+static int fill_render_params(RasterParams& P, const int64_t* first, const int64_t* nfaces, int N, int H, int W,
+                              float blur, int K, int clip, const float* maps, const float* fuv, int fuv_shared, int Ht,
+                              int Wt, float sigma, const float* bg, const float* amb, int mode) {
+  if (!first || !nfaces || !maps || !fuv || !bg) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || Ht <= 0 || Wt <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (!(blur >= 0.0f)) return fail(UR_ERR_INVALID_ARG, "blur_radius must be >= 0");
+  if (mode < 0 || mode > 2) return fail(UR_ERR_INVALID_ARG, "bad blend mode %d", mode);
+  if (mode != UR_BLEND_HARD && !(sigma > 0.0f)) return fail(UR_ERR_INVALID_ARG, "sigma must be > 0 for soft blending");
+  P.first = first; P.nfaces = nfaces; P.N = N; P.H = H; P.W = W; P.K = K; P.blur = blur; P.clip = clip;
+  P.maps = maps; P.fuv = fuv; P.fuv_shared = fuv_shared; P.Ht = Ht; P.Wt = Wt; P.sigma = sigma; P.mode = mode;
+  for (int i = 0; i < 3; ++i) { P.bg[i] = bg[i]; P.amb[i] = amb ? amb[i] : 1.0f; }
+  P.use_amb = amb && !(amb[0] == 1.0f && amb[1] == 1.0f && amb[2] == 1.0f);
+  return UR_OK;
+}
+
+int ur_render_layered_forward(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces,
+                              int N, int64_t total_faces, int H, int W, float blur_radius, int K,
+                              int clip_barycentric_coords, int cull_backfaces, const float* maps,
+                              const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                              const float* background, const float* ambient, int mode, float* image, int32_t* layers,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (!face_verts || !image || !layers) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
+  RasterParams P{};
+  int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
+                              face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (N == 0) return UR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  rc = prep_faces(face_verts, total_faces, blur_radius, cull_backfaces, mesh_first_face, N, H, W, K, workspace,
+                  workspace_bytes, st, P);
+  if (rc) return rc;
+  P.image = image; P.layers = layers;
+  return launch_raster<2>(P, st);
+}
+
+int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_first_face,
+                               const int64_t* mesh_num_faces, int N, int64_t total_faces, int H, int W,
+                               float blur_radius, int K, int clip_barycentric_coords, const float* maps,
+                               const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                               const float* background, const float* ambient, int mode, const int32_t* layers,
+                               const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                               float* grad_face_verts, float* grad_maps, void* stream) {
+  if (!grad_image || !layers || !workspace || !scratch) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (scratch_bytes < ur_backward_scratch_bytes(N, H, W, K)) return fail(UR_ERR_WORKSPACE, "scratch too small");
+  if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
+  if (workspace_bytes < ur_workspace_bytes(total_faces, N, H, W, K)) return fail(UR_ERR_WORKSPACE, "workspace too small");
+  RasterParams P{};
+  int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
+                              face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (N == 0 || (!grad_face_verts && !grad_maps)) return UR_OK;
+  P.bbox = reinterpret_cast<const float4*>(workspace);
+  P.rec = P.bbox + total_faces;
+  P.order = sched_order(workspace, total_faces, N, H, W);
+  P.layers = const_cast<int32_t*>(layers);
+  P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
+  P.scratch = reinterpret_cast<float*>(scratch);
+  P.nbx = (W + 15) / 16;
+  P.nby = (H + 15) / 16;
+  const int64_t blocks = (int64_t)N * P.nbx * P.nby;
+  if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
+  {
+    ProfScope prof(UR_PROFILE_RENDER_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+  }
+  return check_launch("k_render_bwd");
+}
+
+
+// ---- whole render step over equal-sized meshes: camera + rasterizer + shader in one call each way ------------------
+int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
+                             const float* T, float sx, float sy, int N, int V, int F, const int64_t* mesh_first_face,
+                             const int64_t* mesh_num_faces, int H, int W, float blur_radius, int K,
+                             int clip_barycentric_coords, int cull_backfaces, const float* maps, const float* face_uvs,
+                             int face_uvs_shared, int Ht, int Wt, float sigma, const float* background,
+                             const float* ambient, int mode, float* face_verts, float* image, int32_t* layers,
+                             float* zero_grad_face_verts, float* zero_grad_maps, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!verts || !faces || !R || !T || !face_verts || !image || !layers) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (V <= 0 || F < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  const int64_t NF = (int64_t)(N < 0 ? 0 : N) * F;
+  if (NF > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "more than 2^31-1 faces");
+  RasterParams P{};
+  int rc = fill_render_params(P, mesh_first_face, mesh_num_faces, N, H, W, blur_radius, K, clip_barycentric_coords, maps,
+                              face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
+  if (rc) return rc;
+  if (N == 0) return UR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nbins = ((H + 15) / 16) * ((W + 15) / 16);
+  const int64_t n_gfv = (int64_t)F * 9, n_gmap = (int64_t)Ht * Wt * 3;
+  if (F > 0 && F <= kMeshPrepMaxFaces && nbins <= kPrepBins && n_gfv <= 0x7fffffffLL && n_gmap <= 0x7fffffffLL &&
+      N <= 0x7fffffff / nbins && N <= 65535) {
+    const size_t need = ur_workspace_bytes(NF, N, H, W, K);
+    if (workspace_bytes < need) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))
+      return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+    int* binload = nullptr;
+    int* order = nullptr;
+    carve_workspace(workspace, NF, N, H, W, P, binload, order);
+    const int parts = prep_parts(NF, N);
+    hipLaunchKernelGGL(k_project_prep_mesh, dim3((unsigned)parts, (unsigned)N), dim3(256), 0, st, verts, faces, faces_mesh_stride, R, T,
+                       sx, sy, N, V, F, sqrtf(blur_radius), cull_backfaces, H, W, face_verts, const_cast<float4*>(P.bbox),
+                       const_cast<float4*>(P.rec), const_cast<float*>(P.fz), binload, zero_grad_face_verts, (int)n_gfv,
+                       zero_grad_maps, (int)n_gmap);
+    rc = check_launch("k_project_prep_mesh");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bin_order, dim3(1), dim3(1024), 0, st, binload, N * nbins, order, parts, nbins);
+    rc = check_launch("k_bin_order");
+    if (rc) return rc;
+  } else {
+    // large meshes: the per-face kernels (a mesh spread over many workgroups, globally sorted schedule)
+    rc = ur_project_faces(verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, face_verts, stream);
+    if (rc) return rc;
+    rc = prep_faces(face_verts, NF, blur_radius, cull_backfaces, mesh_first_face, N, H, W, K, workspace, workspace_bytes,
+                    st, P);
+    if (rc) return rc;
+    if (zero_grad_face_verts && hipMemsetAsync(zero_grad_face_verts, 0, (size_t)NF * 36, st) != hipSuccess)
+      return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+    if (zero_grad_maps && hipMemsetAsync(zero_grad_maps, 0, (size_t)N * n_gmap * 4, st) != hipSuccess)
+      return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+  }
+  P.image = image; P.layers = layers;
+  return launch_raster<2>(P, st);
+}
+
+int ur_render_meshes_backward(const float* grad_image, const float* verts, const int64_t* faces,
+                              int64_t faces_mesh_stride, const float* R, const float* T, float sx, float sy, int N,
+                              int V, int F, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int H, int W,
+                              float blur_radius, int K, int clip_barycentric_coords, const float* maps,
+                              const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                              const float* background, const float* ambient, int mode, const int32_t* layers,
+                              const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                              float* grad_face_verts, float* grad_maps, int grads_are_zero, float* grad_verts,
+                              float* grad_R, float* grad_T, void* stream) {
+  if (N < 0 || F < 0 || Ht <= 0 || Wt <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  const int64_t NF = (int64_t)N * F;
+  const bool geometry = grad_verts || grad_R || grad_T;
+  if (geometry && !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "geometry gradients need the grad_face_verts buffer");
+  hipStream_t st = (hipStream_t)stream;
+  if (!grads_are_zero && N > 0) {
+    if (grad_face_verts && hipMemsetAsync(grad_face_verts, 0, (size_t)NF * 36, st) != hipSuccess)
+      return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+    if (grad_maps && hipMemsetAsync(grad_maps, 0, (size_t)N * Ht * Wt * 12, st) != hipSuccess)
+      return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
+  }
+  int rc = ur_render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, N, NF, H, W, blur_radius, K,
+                                      clip_barycentric_coords, maps, face_uvs, face_uvs_shared, Ht, Wt, sigma, background,
+                                      ambient, mode, layers, workspace, workspace_bytes, scratch, scratch_bytes,
+                                      geometry ? grad_face_verts : nullptr, grad_maps, stream);
+  if (rc || !geometry) return rc;
+  return ur_project_faces_backward(verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts, grad_verts,
+                                   grad_R, grad_T, stream);
+}
+
+}  // extern "C"
