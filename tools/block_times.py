@@ -38,6 +38,15 @@ show("scan round 0", w[:, 15] - w[:, 0])
 show("fine", w[:, 2] - w[:, 15])
 show("tail (all)", w[:, 5] - w[:, 2])
 show("whole wave", w[:, 5] - w[:, 0])
+if (w[:, 1] > 0).any():  # tail sub-phases (extra stamps of the dev build: after compaction, short sort, deep sort)
+    w14 = tim.view(nblk * 4, 16).cpu()[live][:, 14]
+    t_deep_end = (w14 >> 8).double()
+    show("tail: hide compaction", w[:, 1] - w[:, 2])
+    show("tail: short sort", w[:, 6] - w[:, 1])
+    show("tail: deep sort", t_deep_end - w[:, 6])
+    show("tail: items + composite", w[:, 5] - t_deep_end)
+    nd = (w14 & 255).double()
+    print("deep lists per wave: mean %.2f max %d ; deep sort us per list %.2f" % (float(nd.mean()), int(nd.max()), float(us(t_deep_end - w[:, 6]).sum() / max(1.0, float(nd.sum())))))
 fine = us(w[:, 2] - w[:, 15])
 print("fine phase: batches total %.0f pairs total %.0f (fill %.2f) faces(rects) total %.0f chunks total %.0f" % (float(w[:, 8].sum()), float(w[:, 9].sum()), float(w[:, 9].sum() / (64 * w[:, 8].sum())), float(w[:, 7].sum()), float(w[:, 12].sum())))
 print("fine wave-us: total %.0f ; barrier wait+stage write %.0f ; chunk setup (incl. stage load issue) %.0f ; rest (batches) %.0f -> us per batch %.2f" % (float(fine.sum()), float(us(w[:, 10]).sum()), float(us(w[:, 11]).sum()), float((fine - us(w[:, 10]) - us(w[:, 11])).sum()), float((fine - us(w[:, 10]) - us(w[:, 11])).sum() / w[:, 8].sum())))

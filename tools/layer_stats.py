@@ -19,24 +19,14 @@ fuv = sc["verts_uvs"][sc["faces"]].contiguous()
 img, layers, ws = native.render_layered_forward(fv, first, num, (H, H), blur, K, True, sc["maps"], fuv, True, sigma,
                                                 (1, 1, 1), None, 1)
 torch.cuda.synchronize()
-L = layers.view(B, H // 8, H // 8, K, 6, 64)[:, :, :, :, 0, :]       # fid planes
-alive = (L >= 0).to(torch.int32).cumprod(dim=3)                        # leading run
-m = alive.sum(dim=3)                                                   # (B,TH,TW,64) layers per pixel
+nb = (H // 16) ** 2
+cnt_off = B * nb * 4 * K * 6 * 64                                        # per-pixel layer counts follow the records
+m = layers.view(-1)[cnt_off:cnt_off + B * nb * 4 * 64].view(B, nb, 4, 64)  # (image, bin, wave group, pixel)
 print("items", int(m.sum()), "per image", float(m.sum()) / B, "covered px frac", float((m > 0).float().mean()))
 print("mean layers on covered px", float(m[m > 0].float().mean()), "max", int(m.max()))
-t = m.sum(dim=3)                                                       # per tile
-print("tile items: mean", float(t.float().mean()), "max", int(t.max()), "p99", float(t.float().flatten().quantile(0.99)))
+t = m.sum(dim=3)                                                       # per wave group
+print("group items: mean", float(t.float().mean()), "max", int(t.max()), "p99", float(t.float().flatten().quantile(0.99)))
 tm = m.max(dim=3).values
-print("tile max depth: mean", float(tm.float().mean()), "max", int(tm.max()))
-print("lockstep cost sum(tile maxdepth*64)", int(tm.sum()) * 64, "vs items", int(m.sum()))
-hist = torch.bincount(m.flatten(), minlength=16)[:24]
-print("hist layers/pixel", hist.tolist())
-bins = t.view(B, H // 16, 2, H // 16, 2).sum(dim=(2, 4))
-print("bin items: mean", float(bins.float().mean()), "max", int(bins.max()), "nonempty", int((bins > 0).sum()), "of", bins.numel())
-if os.environ.get("UR_DEBUG") == "13":
-    cot = torch.randn(B, 4, H, H, device=dev)
-    gfv, gm = native.render_layered_backward(cot, first, num, B * F, (H, H), blur, K, True, sc["maps"], fuv, True,
-                                             sigma, (1, 1, 1), None, 1, layers, ws)
-    torch.cuda.synchronize()
-    print("texel claims: fail", float(gm.flatten()[0]), "ok", float(gm.flatten()[1]))
-    print("face claims: fail", float(gfv.flatten()[0]), "ok", float(gfv.flatten()[1]))
+print("group max depth: mean", float(tm.float().mean()), "max", int(tm.max()))
+h = torch.bincount(m.flatten().clamp(max=20), minlength=21)
+print("depth histogram (0..20+):", h.tolist())

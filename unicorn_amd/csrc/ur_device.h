@@ -155,14 +155,22 @@ __device__ __forceinline__ void sample_rgb(const float* __restrict__ map, const 
                                            float& g, float& bl) {
   int onw, one, osw, ose;
   bilin_offsets(b, Ht, Wt, onw, one, osw, ose);
+  // all twelve loads are issued unconditionally (a texel outside the map reads the north-west one instead and is
+  // replaced by 0 afterwards): straight-line code, the loads of several samples can be in flight together
+  const int ene = one >= 0 ? one : onw, esw = osw >= 0 ? osw : onw, ese = ose >= 0 ? ose : onw;
+  float t[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    t[0][c] = map[onw + c]; t[1][c] = map[ene + c]; t[2][c] = map[esw + c]; t[3][c] = map[ese + c];
+  }
   float acc[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     float a = 0.0f;
-    a += map[onw + c] * b.wnw;
-    a += (one >= 0 ? map[one + c] : 0.0f) * b.wne;
-    a += (osw >= 0 ? map[osw + c] : 0.0f) * b.wsw;
-    a += (ose >= 0 ? map[ose + c] : 0.0f) * b.wse;
+    a += t[0][c] * b.wnw;
+    a += (one >= 0 ? t[1][c] : 0.0f) * b.wne;
+    a += (osw >= 0 ? t[2][c] : 0.0f) * b.wsw;
+    a += (ose >= 0 ? t[3][c] : 0.0f) * b.wse;
     acc[c] = a;
   }
   r = acc[0]; g = acc[1]; bl = acc[2];

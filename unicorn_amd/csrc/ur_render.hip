@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/unicorn_render.h"
@@ -898,16 +899,57 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     cnt = s_cnt[lane];
     hide_key = s_hide[lane];
     int n_rel = cnt;
-    if (__any(hide_key != ~0ull && cnt > 0)) {
-      const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(hide_key != ~0ull ? cnt : 0));
-      const int j = keys.compact(hide_key != ~0ull, cnt, maxcnt, hide_key);
-      if (hide_key != ~0ull) n_rel = j;
+    constexpr int kDeep = 8;
+    // lists longer than kDeep are first compacted against the hide key in place (they may live partly in the spill
+    // area); the short ones drop their hidden entries on the way through the register sort below
+    if (__any(hide_key != ~0ull && cnt > kDeep)) {
+      const bool need = hide_key != ~0ull && cnt > kDeep;
+      const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(need ? cnt : 0));
+      const int j = keys.compact(need, cnt, maxcnt, hide_key);
+      if (need) n_rel = j;
     }
     if (!pix_live) n_rel = 0;
-    constexpr int kDeep = 8;
     {
-      // short lists: per-lane selection sort
-      const bool mine = n_rel <= kDeep || n_rel > 64;
+      // short lists (up to kDeep entries): loaded into registers, hidden entries replaced by the all-ones pad (no
+      // real key has that value: depth bits of a finite float), sorted by a fixed compare-exchange network sized by
+      // the longest short list of the wave, stored back.  Keys are unique, so the order is total.
+      const bool small = n_rel <= kDeep;
+      const int maxs = __builtin_amdgcn_readfirstlane(wave_max(small ? n_rel : 0));
+      if (maxs > 0) {
+        unsigned long long e[kDeep];
+#pragma unroll
+        for (int i = 0; i < kDeep; ++i) {
+          e[i] = ~0ull;
+          if (i < maxs) {
+            if (small && i < n_rel) e[i] = keys.get(i);
+            if (e[i] > hide_key) e[i] = ~0ull;
+          }
+        }
+        auto cx = [&](int i, int j) {
+          const bool sw = e[j] < e[i];
+          const unsigned long long lo = sw ? e[j] : e[i], hi = sw ? e[i] : e[j];
+          e[i] = lo; e[j] = hi;
+        };
+        if (maxs > 4) {
+          cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7); cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7); cx(1, 2); cx(5, 6);
+          cx(0, 4); cx(1, 5); cx(2, 6); cx(3, 7); cx(2, 4); cx(3, 5); cx(1, 2); cx(3, 4); cx(5, 6);
+        } else if (maxs > 2) {
+          cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+        } else if (maxs > 1) {
+          cx(0, 1);
+        }
+        if (small) {
+          int kept = 0;
+#pragma unroll
+          for (int i = 0; i < kDeep; ++i) kept += (e[i] != ~0ull) ? 1 : 0;
+          n_rel = kept;
+#pragma unroll
+          for (int i = 0; i < kDeep; ++i)
+            if (i < maxs && i < n_rel) keys.put(i, e[i]);
+        }
+      }
+      // lists longer than a wave (K > 64 only): per-lane selection sort
+      const bool mine = n_rel > 64;
       int sorted = 0;
       while (__any(mine && sorted < n_rel - 1)) {
         if (mine && sorted < n_rel - 1) {
@@ -924,24 +966,35 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       }
       // long lists (pixels in the blur halo of a silhouette vertex): the whole wave sorts one list at a time by
       // rank counting -- lane j holds entry j, the list is broadcast entry by entry, no memory access in the loop
-      unsigned long long deep = __ballot(!mine);
+      // Four lists per round: their entries (the part past the LDS cap sits in the global spill area) are fetched
+      // together, so the global round trips overlap instead of queueing one list behind the other.
+      unsigned long long deep = __ballot(n_rel > kDeep && n_rel <= 64);
       while (deep) {
-        const int l = __builtin_ctzll(deep);
-        deep &= deep - 1;
-        const int ml = __builtin_amdgcn_readlane(n_rel, l);
-        unsigned long long kj = ~0ull;
-        if (lane < ml)
-          kj = (lane < P.cap) ? lds_base[(size_t)lane * 64 + l] : spill_base[(size_t)(lane - P.cap) * 64 + l];
-        const unsigned lo = (unsigned)kj, hi = (unsigned)(kj >> 32);
-        int rank = 0;
-        for (int i = 0; i < ml; ++i) {
-          const unsigned long long ki = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, i) << 32) |
-                                        (unsigned)__builtin_amdgcn_readlane((int)lo, i);
-          rank += (ki < kj) ? 1 : 0;
+        int dl[4], dml[4];
+        unsigned long long dk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          dl[u] = deep ? __builtin_ctzll(deep) : 0;
+          dml[u] = deep ? __builtin_amdgcn_readlane(n_rel, dl[u]) : 0;
+          deep &= deep - 1;
+          dk[u] = ~0ull;
+          if (lane < dml[u])
+            dk[u] = (lane < P.cap) ? lds_base[(size_t)lane * 64 + dl[u]] : spill_base[(size_t)(lane - P.cap) * 64 + dl[u]];
         }
-        if (lane < ml) {
-          if (rank < P.cap) lds_base[(size_t)rank * 64 + l] = kj;
-          else spill_base[(size_t)(rank - P.cap) * 64 + l] = kj;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long kj = dk[u];
+          const unsigned lo = (unsigned)kj, hi = (unsigned)(kj >> 32);
+          int rank = 0;
+          for (int i = 0; i < dml[u]; ++i) {
+            const unsigned long long ki = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, i) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)lo, i);
+            rank += (ki < kj) ? 1 : 0;
+          }
+          if (lane < dml[u]) {
+            if (rank < P.cap) lds_base[(size_t)rank * 64 + dl[u]] = kj;
+            else spill_base[(size_t)(rank - P.cap) * 64 + dl[u]] = kj;
+          }
         }
       }
     }
@@ -954,49 +1007,78 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     s_pre[lane] = pre;
     // the staging buffers are dead once the fine step is over (every wave is past its last barrier): this wave's
     // slice of them carries the batch's (alpha, r, g, b) from the lanes that computed them to the pixels' owners
-    float4* s_res = s_rec + wave * 64;
+    float4* s_res = s_rec + wave * 128;
     int32_t* lay_tile = P.layers + tile_id * (int64_t)K * 6 * 64;  // [K][6 words][64 lanes]
     int32_t* lay = lay_tile + lane;
     float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
-    for (int base = 0; base < total; base += 64) {
-      const int item = base + lane;
-      // owner of item: the pixels whose first item falls inside the batch mark that slot with lane + 1, slot 0 takes
-      // the pixel that holds item `base`, and a running maximum spreads the marks to the right
-      marks[lane] = 0;
-      const int l0 = 63 - __builtin_clzll(__ballot(m > 0 && pre <= base));
-      if (m > 0 && pre > base && pre < base + 64) marks[pre - base] = (unsigned char)(lane + 1);
-      const int l = wave_scan_max(lane == 0 ? l0 + 1 : (int)marks[lane]) - 1;
-      float va = 0.0f, vr = 0.0f, vg = 0.0f, vb = 0.0f;
-      if (item < total) {
-        const int k = item - s_pre[l];
-        const unsigned long long key = (k < P.cap) ? lds_base[(size_t)k * 64 + l]
-                                                    : spill_base[(size_t)(k - P.cap) * 64 + l];
-        const int fid = key_face(key);
-        const float qx = pix_to_ndc(W - 1 - (tx0 + xs * (l & 7)), W, H);
-        const float qy = pix_to_ndc(H - 1 - (ty0 + xs * (l >> 3)), H, W);
-        const Face fc = load_face(P.rec, fid);
-        const float* fu = face_uv_row(P, n, fid);
-        const float fu0 = fu[0], fu1 = fu[1], fu2 = fu[2], fu3 = fu[3], fu4 = fu[4], fu5 = fu[5];
+    // One round takes 64 U items, U per lane.  The item phase is a chain of dependent memory round trips (key ->
+    // record + UVs -> texels) with little arithmetic in between, so two items per lane are walked through it side by
+    // side (every stage written for both before the next begins, no branches in between: lanes past the end redo the
+    // last item and only their stores are masked), which lets their loads overlap.  Groups with at most 64 items
+    // left take the one-item form.
+    auto round = [&](auto UC, int base) {
+      constexpr int U = decltype(UC)::value;
+      int il[U], ik[U], ifid[U];
+      bool act[U];
+      // owner of an item: the pixels whose first item falls inside the 64-item batch mark that slot with lane + 1,
+      // slot 0 takes the pixel that holds the batch's first item, and a running maximum spreads the marks to the right
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int b0 = base + 64 * u;
+        marks[lane] = 0;
+        const int l0 = 63 - __builtin_clzll(__ballot(m > 0 && pre <= b0));
+        if (m > 0 && pre > b0 && pre < b0 + 64) marks[pre - b0] = (unsigned char)(lane + 1);
+        il[u] = wave_scan_max(lane == 0 ? l0 + 1 : (int)marks[lane]) - 1;
+        act[u] = b0 + lane < total;
+        ik[u] = min(b0 + lane, total - 1) - s_pre[il[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        unsigned long long key = lds_base[(size_t)min(ik[u], P.cap - 1) * 64 + il[u]];
+        if (ik[u] >= P.cap) key = spill_base[(size_t)(ik[u] - P.cap) * 64 + il[u]];
+        ifid[u] = key_face(key);
+      }
+      Face fc[U];
+      float fu[U][6];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        fc[u] = load_face(P.rec, ifid[u]);
+        const float* fp = face_uv_row(P, n, ifid[u]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fu[u][q] = fp[q];
+      }
+      float va[U], vr[U], vg[U], vb[U];
+      Bilin bl[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float qx = pix_to_ndc(W - 1 - (tx0 + xs * (il[u] & 7)), W, H);
+        const float qy = pix_to_ndc(H - 1 - (ty0 + xs * (il[u] >> 3)), H, W);
         Eval ev;
-        eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
-        va = layer_alpha(ev.sd, true, P.sigma, P.mode);
-        const float u = (ev.c0 * fu0 + ev.c1 * fu2) + ev.c2 * fu4;
-        const float v = (ev.c0 * fu1 + ev.c1 * fu3) + ev.c2 * fu5;
-        const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
-        sample_rgb(map, bl, P.Ht, P.Wt, vr, vg, vb);
-        if (P.use_amb) { vr *= P.amb[0]; vg *= P.amb[1]; vb *= P.amb[2]; }
+        eval_face(fc[u], qx, qy, P.blur, P.clip != 0, ev);
+        va[u] = layer_alpha(ev.sd, true, P.sigma, P.mode);
+        const float tu = (ev.c0 * fu[u][0] + ev.c1 * fu[u][2]) + ev.c2 * fu[u][4];
+        const float tv = (ev.c0 * fu[u][1] + ev.c1 * fu[u][3]) + ev.c2 * fu[u][5];
+        bl[u] = bilin_setup(tu, tv, P.Ht, P.Wt);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) sample_rgb(map, bl[u], P.Ht, P.Wt, vr[u], vg[u], vb[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (P.use_amb) { vr[u] *= P.amb[0]; vg[u] *= P.amb[1]; vb[u] *= P.amb[2]; }
         // the layer record for the backward, written by whoever computed it (plane 1, the transmittance in front of
         // the layer, comes from the pixel's owner below)
-        int32_t* le = lay_tile + (int64_t)k * 6 * 64 + l;
-        le[0] = fid;
-        le[128] = __float_as_int(va);
-        le[192] = __float_as_int(vr);
-        le[256] = __float_as_int(vg);
-        le[320] = __float_as_int(vb);
+        if (act[u]) {
+          int32_t* le = lay_tile + (int64_t)ik[u] * 6 * 64 + il[u];
+          le[0] = ifid[u];
+          le[128] = __float_as_int(va[u]);
+          le[192] = __float_as_int(vr[u]);
+          le[256] = __float_as_int(vg[u]);
+          le[320] = __float_as_int(vb[u]);
+        }
+        s_res[64 * u + lane] = make_float4(va[u], vr[u], vg[u], vb[u]);
       }
-      s_res[lane] = make_float4(va, vr, vg, vb);
-      // owners composite their items of this batch, in depth order
-      const int s0 = max(pre, base), e0 = min(pre + m, base + 64);
+      // owners composite their items of this round, in depth order
+      const int s0 = max(pre, base), e0 = min(pre + m, base + 64 * U);
       const int nloop = __builtin_amdgcn_readfirstlane(wave_max(max(e0 - s0, 0)));
       for (int t = 0; t < nloop; ++t) {
         if (s0 + t < e0) {
@@ -1006,7 +1088,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           occ = occ * (1.0f - c.x);
         }
       }
-    }
+    };
+    int base = 0;
+    for (; base + 64 < total; base += 128) round(std::integral_constant<int, 2>{}, base);
+    if (base < total) round(std::integral_constant<int, 1>{}, base);
     P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] = m;  // per-pixel layer count
     if (pix_live) {
       const int64_t hw = (int64_t)H * W;
