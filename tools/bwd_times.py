@@ -45,3 +45,9 @@ for lo, hi in ((0, 4), (4, 9), (9, 51)):
     sel = (w[:, 6] > lo) & (w[:, 6] <= hi)
     if sel.any():
         print("  waves with max depth in (%d,%d]: %d ; scan %.1f ; phase A %.1f ; phase B %.1f" % (lo, hi, int(sel.sum()), float(us(w[sel, 1] - w[sel, 0]).mean()), float(us(w[sel, 2] - w[sel, 1]).mean()), float(us(w[sel, 3] - w[sel, 2]).mean())))
+if w.shape[1] > 9 and float(w[:, 9].sum()) > 0:  # dev counters of the timing build: scatter fallbacks to global atomics
+    items = float(w[:, 9].sum())
+    print("items %.0f ; face-table fallbacks %.0f (%.1f%% of items) ; texel-table fallbacks %.0f (%.1f%% of 4 x items)" % (
+        items, float(w[:, 7].sum()), 100 * float(w[:, 7].sum()) / items, float(w[:, 8].sum()), 100 * float(w[:, 8].sum()) / (4 * items)))
+    nb = torch.ceil(w[:, 9] / 64)
+    print("phase B us per batch: %.2f" % (float(us(w[:, 3] - w[:, 2]).sum()) / float(nb.sum())))

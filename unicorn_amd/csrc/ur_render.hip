@@ -964,39 +964,46 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           ++sorted;
         }
       }
-      // long lists (pixels in the blur halo of a silhouette vertex): the whole wave sorts one list at a time by
-      // rank counting -- lane j holds entry j, the list is broadcast entry by entry, no memory access in the loop
-      // Four lists per round: their entries (the part past the LDS cap sits in the global spill area) are fetched
-      // together, so the global round trips overlap instead of queueing one list behind the other.
-      unsigned long long deep = __ballot(n_rel > kDeep && n_rel <= 64);
-      while (deep) {
-        int dl[4], dml[4];
-        unsigned long long dk[4];
+      // long lists (pixels in the blur halo of a silhouette vertex, 9..64 entries): sorted across lanes by a bitonic
+      // network over lane groups of 16, 32 or 64 -- four, two or one list per round, entry j of a list in lane j of
+      // its group, padded with all-ones keys.  The lists of a round are fetched together (the part past the LDS cap
+      // sits in the global spill area), so their round trips overlap.
+      auto bitonic_pass = [&](auto WC, unsigned long long todo) {
+        constexpr int Wd = decltype(WC)::value, per = 64 / Wd;
+        const int sub = lane / Wd, j = lane & (Wd - 1);
+        while (todo) {
+          int myl = 0;
+          bool have = false;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          dl[u] = deep ? __builtin_ctzll(deep) : 0;
-          dml[u] = deep ? __builtin_amdgcn_readlane(n_rel, dl[u]) : 0;
-          deep &= deep - 1;
-          dk[u] = ~0ull;
-          if (lane < dml[u])
-            dk[u] = (lane < P.cap) ? lds_base[(size_t)lane * 64 + dl[u]] : spill_base[(size_t)(lane - P.cap) * 64 + dl[u]];
-        }
+          for (int u = 0; u < per; ++u) {
+            const bool any = todo != 0ull;
+            const int l = any ? __builtin_ctzll(todo) : 0;
+            todo &= todo - 1;
+            if (sub == u) { myl = l; have = any; }
+          }
+          const int nl = __shfl(n_rel, myl, 64);  // every lane takes part: a masked-off lane cannot be read from
+          const int myn = have ? nl : 0;
+          unsigned long long v = ~0ull;
+          if (j < myn) v = (j < P.cap) ? lds_base[(size_t)j * 64 + myl] : spill_base[(size_t)(j - P.cap) * 64 + myl];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned long long kj = dk[u];
-          const unsigned lo = (unsigned)kj, hi = (unsigned)(kj >> 32);
-          int rank = 0;
-          for (int i = 0; i < dml[u]; ++i) {
-            const unsigned long long ki = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, i) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)lo, i);
-            rank += (ki < kj) ? 1 : 0;
-          }
-          if (lane < dml[u]) {
-            if (rank < P.cap) lds_base[(size_t)rank * 64 + dl[u]] = kj;
-            else spill_base[(size_t)(rank - P.cap) * 64 + dl[u]] = kj;
+          for (int k = 2; k <= Wd; k <<= 1)
+#pragma unroll
+            for (int d = k >> 1; d > 0; d >>= 1) {
+              const unsigned long long o = __shfl_xor(v, d, 64);
+              const bool take_min = ((j & d) == 0) == ((j & k) == 0);
+              v = (take_min == (o < v)) ? o : v;
+            }
+          if (j < myn) {
+            if (j < P.cap) lds_base[(size_t)j * 64 + myl] = v;
+            else spill_base[(size_t)(j - P.cap) * 64 + myl] = v;
           }
         }
-      }
+      };
+      const unsigned long long d16 = __ballot(n_rel > kDeep && n_rel <= 16), d32 = __ballot(n_rel > 16 && n_rel <= 32),
+                               d64 = __ballot(n_rel > 32 && n_rel <= 64);
+      bitonic_pass(std::integral_constant<int, 16>{}, d16);
+      bitonic_pass(std::integral_constant<int, 32>{}, d32);
+      bitonic_pass(std::integral_constant<int, 64>{}, d64);
     }
     const int m = n_rel;  // layers of this pixel that matter, front to back in slots [0, m)
     const int incl = wave_scan_add(m);
