@@ -456,21 +456,16 @@ struct KeyList {
     if (i < cap) lds[(size_t)i * 64] = v; else spill[(size_t)(i - cap) * 64] = v;
   }
   // Keep, in order, the entries <= bound of this lane's first n entries (lanes with !need keep everything and
-  // return n); mx = the largest n among the lanes that need it (wave-uniform).  The spilled part is read eight
-  // entries at a time so that the global loads overlap instead of forming one dependent chain.
+  // return n); mx = the largest n among the lanes that need it (wave-uniform).  Entries are read eight at a time
+  // (LDS or spill alike), so that the loads overlap instead of forming one dependent chain; a write position never
+  // passes the entries still to be read.
   __device__ __forceinline__ int compact(bool need, int n, int mx, unsigned long long bound) const {
-    if (!need) n = 0;  // nothing to do in the loops below
+    if (!need) n = 0;  // nothing to do in the loop below
     int j = 0;
-    const int lds_n = mx < cap ? mx : cap;
-    for (int i = 0; i < lds_n; ++i)
-      if (i < n) {
-        const unsigned long long kk = lds[(size_t)i * 64];
-        if (kk <= bound) { put(j, kk); ++j; }
-      }
-    for (int i0 = cap; i0 < mx; i0 += 8) {
+    for (int i0 = 0; i0 < mx; i0 += 8) {
       unsigned long long t[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t[q] = (i0 + q < n) ? spill[(size_t)(i0 + q - cap) * 64] : ~0ull;
+      for (int q = 0; q < 8; ++q) t[q] = (i0 + q < n) ? get(i0 + q) : ~0ull;
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         if (i0 + q < n && t[q] <= bound) { put(j, t[q]); ++j; }
