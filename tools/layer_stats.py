@@ -5,9 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unicorn_amd import native, synth, ops
 from unicorn_amd.renderer import Renderer
 
-B, H, K = 32, 128, 50
+B, H, K, LEVEL = [int(x) for x in os.environ.get('UR_DEV_SHAPE', '32,128,50,3').split(',')]  # batch, image, K, icosphere level
 dev = torch.device("cuda", 0)
-sc = synth.make_scene(B, level=3, tex_size=64, seed=0, device=dev)
+sc = synth.make_scene(B, level=LEVEL, tex_size=64, seed=0, device=dev)
 s = 1.0 / math.tan(math.radians(15.0))
 F = sc["faces"].shape[0]
 fv = native.project_faces(sc["verts"], sc["faces"], sc["R"], sc["T"], s, s)

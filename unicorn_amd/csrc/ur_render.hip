@@ -3,7 +3,7 @@
 // Execution model (DESIGN.md 5 has the long version):
 //   * k_face_prep: one thread per face -> bounding box, per-face record (corners, denominators, RN reciprocals), and
 //     a per-bin load count; k_bin_order sorts the 16x16-pixel bins of all meshes heaviest first;
-//   * k_raster<MODE>: one workgroup (4 waves) per bin, taken from that schedule.  Coarse step: the workgroup scans the
+//   * k_raster<MODE, BIGK>: one workgroup (4 waves) per bin, taken from that schedule.  Coarse step: the workgroup scans the
 //     mesh's face boxes (up to 8 coalesced float4 per lane), ballot + popcount prefix packs survivors into one bin
 //     list in LDS -- no atomics, deterministic; rounds of 2048 faces, the list cannot overflow.  Fine step: 64 bin
 //     faces at a time staged in LDS (double buffered).  MODE 0 (fragments): lane = pixel, faces walked one by one.
@@ -475,7 +475,9 @@ struct KeyList {
 };
 
 // MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
-template <int MODE>
+// BIGK (K > 64): the code for lists longer than a wave and for scanning full lists that sit mostly in the spill area
+// -- kept out of the K <= 64 build, whose register allocation it would disturb (1 % on the headline workload)
+template <int MODE, bool BIGK>
 __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BW = 16, BH = 16, WPB = 4;
@@ -700,12 +702,24 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           keys.put(cnt, key);
           ++cnt;
         } else {
-          // list full: replace the current maximum when the newcomer is smaller (rare path)
+          // list full: the newcomer replaces the current maximum when it is smaller (rare path)
           unsigned long long mx = 0;
           int im = 0;
-          for (int i = 0; i < K; ++i) {
-            const unsigned long long kk = keys.get(i);
-            if (kk > mx) { mx = kk; im = i; }
+          if constexpr (BIGK) {
+            // most of a long list sits in the global spill area: read eight entries at a time
+            for (int i0 = 0; i0 < K; i0 += 8) {
+              unsigned long long t[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) t[q] = (i0 + q < K) ? keys.get(i0 + q) : 0ull;
+#pragma unroll
+              for (int q = 0; q < 8; ++q)
+                if (t[q] > mx) { mx = t[q]; im = i0 + q; }
+            }
+          } else {
+            for (int i = 0; i < K; ++i) {
+              const unsigned long long kk = keys.get(i);
+              if (kk > mx) { mx = kk; im = i; }
+            }
           }
           if (key < mx) keys.put(im, key);
         }
@@ -943,20 +957,22 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
             if (i < maxs && i < n_rel) keys.put(i, e[i]);
         }
       }
-      // lists longer than a wave (K > 64 only): per-lane selection sort
-      const bool mine = n_rel > 64;
-      int sorted = 0;
-      while (__any(mine && sorted < n_rel - 1)) {
-        if (mine && sorted < n_rel - 1) {
-          unsigned long long best = keys.get(sorted);
-          const unsigned long long cur = best;
-          int ib = sorted;
-          for (int i = sorted + 1; i < n_rel; ++i) {
-            const unsigned long long kk = keys.get(i);
-            if (kk < best) { best = kk; ib = i; }
+      if constexpr (BIGK) {
+        // lists longer than 128 entries (K > 128 only): per-lane selection sort
+        const bool mine = n_rel > 128;
+        int sorted = 0;
+        while (__any(mine && sorted < n_rel - 1)) {
+          if (mine && sorted < n_rel - 1) {
+            unsigned long long best = keys.get(sorted);
+            const unsigned long long cur = best;
+            int ib = sorted;
+            for (int i = sorted + 1; i < n_rel; ++i) {
+              const unsigned long long kk = keys.get(i);
+              if (kk < best) { best = kk; ib = i; }
+            }
+            if (ib != sorted) { keys.put(ib, cur); keys.put(sorted, best); }
+            ++sorted;
           }
-          if (ib != sorted) { keys.put(ib, cur); keys.put(sorted, best); }
-          ++sorted;
         }
       }
       // long lists (pixels in the blur halo of a silhouette vertex, 9..64 entries): sorted across lanes by a bitonic
@@ -999,6 +1015,49 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       bitonic_pass(std::integral_constant<int, 16>{}, d16);
       bitonic_pass(std::integral_constant<int, 32>{}, d32);
       bitonic_pass(std::integral_constant<int, 64>{}, d64);
+      if constexpr (BIGK) {
+        // 65..128 entries (K > 64 only): one list at a time, two entries per lane (entry e in lane e & 63, register
+        // e >> 6); the distance-64 exchange is between a lane's own two registers
+        unsigned long long d128 = __ballot(n_rel > 64 && n_rel <= 128);
+        while (d128) {
+          const int l = __builtin_ctzll(d128);
+          d128 &= d128 - 1;
+          const int nl = __builtin_amdgcn_readlane(n_rel, l);
+          unsigned long long v[2];
+  #pragma unroll
+          for (int r2 = 0; r2 < 2; ++r2) {
+            const int e = lane + 64 * r2;
+            v[r2] = ~0ull;
+            if (e < nl) v[r2] = (e < P.cap) ? lds_base[(size_t)e * 64 + l] : spill_base[(size_t)(e - P.cap) * 64 + l];
+          }
+  #pragma unroll
+          for (int k = 2; k <= 128; k <<= 1)
+  #pragma unroll
+            for (int d = k >> 1; d > 0; d >>= 1) {
+              if (d == 64) {
+                const bool sw = v[1] < v[0];
+                const unsigned long long lo = sw ? v[1] : v[0], hi = sw ? v[0] : v[1];
+                v[0] = lo; v[1] = hi;
+              } else {
+  #pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                  const int e = lane + 64 * r2;
+                  const unsigned long long o = __shfl_xor(v[r2], d, 64);
+                  const bool take_min = ((e & d) == 0) == ((e & k) == 0);
+                  v[r2] = (take_min == (o < v[r2])) ? o : v[r2];
+                }
+              }
+            }
+  #pragma unroll
+          for (int r2 = 0; r2 < 2; ++r2) {
+            const int e = lane + 64 * r2;
+            if (e < nl) {
+              if (e < P.cap) lds_base[(size_t)e * 64 + l] = v[r2];
+              else spill_base[(size_t)(e - P.cap) * 64 + l] = v[r2];
+            }
+          }
+        }
+      }
     }
     const int m = n_rel;  // layers of this pixel that matter, front to back in slots [0, m)
     const int incl = wave_scan_add(m);
@@ -1173,20 +1232,25 @@ size_t raster_spill_bytes(int64_t total_faces, int N, int H, int W, int K) {
   return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
 }
 
-template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
+template <int MODE, bool BIGK> int launch_raster_k(RasterParams P, hipStream_t st) {
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
   P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K);
   const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static LdsSlot lds_slot;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE>), lds, lds_slot)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE, BIGK>), lds, lds_slot)) return rc;
   const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
   {
     ProfScope prof(MODE == 2 ? UR_PROFILE_RASTER_FWD : UR_PROFILE_OTHER, st);
-    hipLaunchKernelGGL((k_raster<MODE>), dim3((unsigned)blocks), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((k_raster<MODE, BIGK>), dim3((unsigned)blocks), dim3(256), lds, st, P);
   }
   return check_launch("k_raster");
+}
+
+template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
+  if (MODE != 1 && P.K > 64) return launch_raster_k<MODE, true>(P, st);
+  return launch_raster_k<MODE, false>(P, st);
 }
 
 // workspace = [bbox: NF float4][records: NF x 5 float4][nearest depth: NF float, padded to 16 B]
