@@ -50,7 +50,10 @@ if (w[:, 1] > 0).any():  # tail sub-phases (extra stamps of the dev build: after
 fine = us(w[:, 2] - w[:, 15])
 print("fine phase: batches total %.0f pairs total %.0f (fill %.2f) faces(rects) total %.0f chunks total %.0f" % (float(w[:, 8].sum()), float(w[:, 9].sum()), float(w[:, 9].sum() / (64 * w[:, 8].sum())), float(w[:, 7].sum()), float(w[:, 12].sum())))
 print("fine wave-us: total %.0f ; barrier wait+stage write %.0f ; chunk setup (incl. stage load issue) %.0f ; rest (batches) %.0f -> us per batch %.2f" % (float(fine.sum()), float(us(w[:, 10]).sum()), float(us(w[:, 11]).sum()), float((fine - us(w[:, 10]) - us(w[:, 11])).sum()), float((fine - us(w[:, 10]) - us(w[:, 11])).sum() / w[:, 8].sum())))
+n_lock = torch.floor(w[:, 12] / 65536.0); d_lock = torch.floor(w[:, 13] / 65536.0)
+w[:, 12] = w[:, 12] - n_lock * 65536.0; w[:, 13] = w[:, 13] - d_lock * 65536.0
+print("lockstep (lane = pixel) sections: faces total %.0f taking %.0f wave-us -> us per face %.2f" % (float(n_lock.sum()), float(us(d_lock).sum()), float(us(d_lock).sum()) / max(1.0, float(n_lock.sum()))))
 hv = torch.argsort(fine, descending=True)[:6]
 for i in hv.tolist():
-    print("  heavy wave: fine %.1f us, batches %d, pairs %d, rects %d, chunks %d, list_n %d, barrier %.1f, setup %.1f, compactions %d taking %.1f us" % (float(fine[i]), int(w[i, 8]), int(w[i, 9]), int(w[i, 7]), int(w[i, 12]), int(w[i, 13]), float(us(w[i, 10])), float(us(w[i, 11])), int(w[i, 4]), float(us(w[i, 3]))))
+    print("  heavy wave: fine %.1f us, batches %d, pairs %d, rects %d, chunks %d, list_n %d, barrier %.1f, setup %.1f, compactions %d taking %.1f us" % (float(fine[i]), int(w[i, 8]), int(w[i, 9]), int(w[i, 7]), int(w[i, 12]), int(w[i, 13]), float(us(w[i, 10])), float(us(w[i, 11])), int(w[i, 4]), float(us(w[i, 3]))) + " ; lockstep faces %d taking %.1f us" % (int(n_lock[i]), float(us(d_lock[i]))))
 print("in-loop compactions: %d taking %.0f wave-us" % (int(w[:, 4].sum()), float(us(w[:, 3]).sum())))

@@ -385,6 +385,7 @@ struct RasterParams {
   int clip;
   int nbx, nby;  // bins per row / column
   int cap;       // K-list slots per lane held in LDS
+  int KL;        // K-list capacity (list_cap(K) >= K)
   int64_t total_faces;
   const int* order;  // workgroup -> (mesh * bins + bin), heaviest bins first
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
@@ -429,6 +430,12 @@ constexpr int kBinCap = 256 * kScanQ;  // faces per scan round = bin-list entrie
 constexpr int kSub = 64;         // faces staged in LDS per fine step
 constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU (see raster_cap)
 constexpr int kPreStride = 96;   // ints per wave in the pair-prefix array: 65 prefix entries, then 64 byte marks
+
+// Capacity of a pixel's candidate list while faces are being collected.  The K nearest of all candidates are among the
+// KL nearest for any KL >= K, so the lists may run longer than K and are cut to K after the final sort -- exact, and
+// a list reaches its capacity (where every further candidate costs a scan of the whole list) far less often than it
+// reaches K.  Up to 64 (128) entries a list is still sorted by one wave-wide network.
+__host__ __device__ inline int list_cap(int K) { return K <= 64 ? (2 * K < 64 ? 2 * K : 64) : (K <= 128 ? 128 : K); }
 
 // where the per-pixel layer counts start inside `layers` (after the [group][K][6][64] records)
 __host__ __device__ inline int64_t layer_counts_offset(int N, int nbx, int nby, int K) {
@@ -475,7 +482,7 @@ struct KeyList {
 };
 
 // MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
-// BIGK (K > 64): the code for lists longer than a wave and for scanning full lists that sit mostly in the spill area
+// BIGK (list capacity > 64): the code for lists longer than a wave and for scanning full lists that sit mostly in the spill area
 // -- kept out of the K <= 64 build, whose register allocation it would disturb (1 % on the headline workload)
 template <int MODE, bool BIGK>
 __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
@@ -501,7 +508,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   const int n = item / (P.nbx * P.nby);
   const int b = item - n * (P.nbx * P.nby);
   const int by = b / P.nbx, bx = b - by * P.nbx;
-  const int H = P.H, W = P.W, K = P.K;
+  const int H = P.H, W = P.W, K = P.K, KL = P.KL;
 
   // bin extents in pixel-centre NDC (columns x0..x1, rows y0..y1, clamped to the image)
   const int bx0 = bx * BW, by0 = by * BH;
@@ -530,7 +537,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   KeyList keys;
   keys.cap = P.cap;
   keys.lds = s_keys_all + (size_t)wave * P.cap * 64 + lane;
-  keys.spill = P.spill + (tile_live ? tile_id : 0) * (int64_t)(K - P.cap) * 64 + lane;
+  keys.spill = P.spill + (tile_live ? tile_id : 0) * (int64_t)(KL - P.cap) * 64 + lane;
   int cnt = 0;       // entries in this lane's list
   int tl_count = 0;  // MODE 1: faces appended to this tile's list (wave-uniform)
   // MODE 2 only: depth of the nearest hit found so far that hides everything behind it (alpha == 1 and
@@ -548,9 +555,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   int32_t* s_cnt = s_cnt_all + wave * 64;
   unsigned long long* s_hide = s_hide_all + wave * 64;
   unsigned long long* const lds_keys = s_keys_all + (size_t)wave * P.cap * 64;
-  unsigned long long* const spill_keys = P.spill + (tile_live ? tile_id : 0) * (int64_t)(K - P.cap) * 64;
+  unsigned long long* const spill_keys = P.spill + (tile_live ? tile_id : 0) * (int64_t)(KL - P.cap) * 64;
   unsigned long long last_hk = ~0ull;  // hide key this lane's list was last compacted against
   bool any_stale = false;              // wave-uniform: some pixel's hide key moved since the last compaction
+  int compact_at = 0;                  // wave-uniform: longest list at which the next in-loop compaction is due (0: the LDS cap)
   float pxc[8], pyc[8];                // the tile's 8 column / 8 row centres (wave-uniform)
   unsigned livecols = 0, liverows = 0;
   if (MODE == 2) {
@@ -698,7 +706,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         }
         if (MODE == 2 && key > hide_key) {
           // behind a hit that hides the rest: irrelevant to the blend
-        } else if (cnt < K) {
+        } else if (cnt < KL) {
           keys.put(cnt, key);
           ++cnt;
         } else {
@@ -707,18 +715,22 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           int im = 0;
           if constexpr (BIGK) {
             // most of a long list sits in the global spill area: read eight entries at a time
-            for (int i0 = 0; i0 < K; i0 += 8) {
+            for (int i0 = 0; i0 < KL; i0 += 8) {
               unsigned long long t[8];
 #pragma unroll
-              for (int q = 0; q < 8; ++q) t[q] = (i0 + q < K) ? keys.get(i0 + q) : 0ull;
+              for (int q = 0; q < 8; ++q) t[q] = (i0 + q < KL) ? keys.get(i0 + q) : 0ull;
 #pragma unroll
               for (int q = 0; q < 8; ++q)
                 if (t[q] > mx) { mx = t[q]; im = i0 + q; }
             }
           } else {
-            for (int i = 0; i < K; ++i) {
-              const unsigned long long kk = keys.get(i);
-              if (kk > mx) { mx = kk; im = i; }
+            for (int i0 = 0; i0 < KL; i0 += 4) {
+              unsigned long long t[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) t[q] = (i0 + q < KL) ? keys.get(i0 + q) : 0ull;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (t[q] > mx) { mx = t[q]; im = i0 + q; }
             }
           }
           if (key < mx) keys.put(im, key);
@@ -797,14 +809,19 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
             // compacted view: lane r holds the r-th face that has pairs
             const int cpre = s_fpre[lane], cend = s_fpre[lane + 1];
             const unsigned cinfo = s_finfo[lane];
-            const int lim = min(P.cap, K);
+            const int lim = min(P.cap, KL);
             int r0 = 0;
             while (r0 < nfp) {
               // how many faces can go the pair way: each adds at most one entry to any pixel's list, and no list
-              // may pass K (there the exact keep-the-K-smallest rule takes over, lane = pixel)
+              // may pass its capacity KL (there the exact keep-the-KL-smallest rule takes over, lane = pixel)
               int c2 = s_cnt[lane];
               int cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
-              if (any_stale && cmax + (nfp - r0) > lim) {
+              // Compaction is due when the longest list would leave LDS, or run out of room below K, with the faces at
+              // hand.  Where the lists stay beyond the LDS cap even after a compaction (dense meshes: deep lists),
+              // repeating it at every batch costs more than the batch; the next one then waits until the longest
+              // list has doubled (the tail compacts every list once more anyway).
+              const int due = compact_at > lim ? compact_at : lim;
+              if (any_stale && (cmax + (nfp - r0) > due || cmax + min(nfp - r0, 4) > KL)) {
                 // compact the lists whose hide key moved: drop what the nearest hiding hit made irrelevant
                 const unsigned long long hk = s_hide[lane];
                 const bool need = (hk != last_hk) && c2 > 0;
@@ -814,8 +831,9 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 last_hk = hk;
                 any_stale = false;
                 cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
+                compact_at = cmax < lim ? 0 : min(KL, 2 * cmax);
               }
-              const int room = K - cmax;
+              const int room = KL - cmax;
               if (room < min(nfp - r0, 4)) {
                 const int r1 = min(nfp, r0 + 8);
                 cnt = c2;
@@ -1059,7 +1077,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         }
       }
     }
-    const int m = n_rel;  // layers of this pixel that matter, front to back in slots [0, m)
+    const int m = min(n_rel, K);  // layers of this pixel that matter, front to back in slots [0, m): the K nearest
     const int incl = wave_scan_add(m);
     const int pre = incl - m;
     const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -1169,9 +1187,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   const int64_t ebase = (((int64_t)n * H + y) * W + x) * K;
   unsigned long long last_key = 0;
   bool first_take = true;
-  const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(cnt));
+  const int nout = min(cnt, K);  // the list may hold more candidates than K (list_cap): the K nearest go out
+  const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(nout));
   for (int k = 0; k < maxcnt; ++k) {
-    if (k < cnt) {
+    if (k < nout) {
       unsigned long long best = ~0ull;
       for (int i = 0; i < cnt; ++i) {
         const unsigned long long kk = keys.get(i);
@@ -1193,9 +1212,9 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       }
     }
   }
-  // padding: for every pixel of the tile the slots [cnt, K) are written by lanes that sweep k (contiguous stores)
+  // padding: for every pixel of the tile the slots [nout, K) are written by lanes that sweep k (contiguous stores)
   for (int p = 0; p < 64; ++p) {
-    const int pcnt = __builtin_amdgcn_readlane(cnt, p);
+    const int pcnt = __builtin_amdgcn_readlane(nout, p);
     const int qx = tx0 + xs * (p & 7), qy = ty0 + xs * (p >> 3);
     if (qx >= W || qy >= H) continue;
     const int64_t qbase = (((int64_t)n * H + qy) * W + qx) * K;
@@ -1221,20 +1240,22 @@ constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4
 // +9 % with three workgroups per CU, 20480 faces at 256^2 / K=100 +12 % with two), so the budget follows the mesh's
 // face density on the image: faces per pixel >= 0.2 -> three workgroups per CU, and two when K > 64 as well.
 int raster_cap(int64_t total_faces, int N, int H, int W, int K) {
+  const int KL = list_cap(K);
   const double density = (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W);
   const size_t budget = density < 0.2 ? (size_t)kLdsBudget : (K > 64 ? (size_t)80 * 1024 : (size_t)52 * 1024);
   const int fit = (int)((budget - kRasterFixedLds) / (4 * 64 * 8));
-  return K < fit ? K : fit;
+  return KL < fit ? KL : fit;
 }
 
 size_t raster_spill_bytes(int64_t total_faces, int N, int H, int W, int K) {
-  const int over = K - raster_cap(total_faces, N, H, W, K);
+  const int over = list_cap(K) - raster_cap(total_faces, N, H, W, K);
   return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
 }
 
 template <int MODE, bool BIGK> int launch_raster_k(RasterParams P, hipStream_t st) {
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
+  P.KL = list_cap(P.K);
   P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K);
   const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static LdsSlot lds_slot;
@@ -1249,7 +1270,7 @@ template <int MODE, bool BIGK> int launch_raster_k(RasterParams P, hipStream_t s
 }
 
 template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
-  if (MODE != 1 && P.K > 64) return launch_raster_k<MODE, true>(P, st);
+  if (MODE != 1 && list_cap(P.K) > 64) return launch_raster_k<MODE, true>(P, st);
   return launch_raster_k<MODE, false>(P, st);
 }
 
