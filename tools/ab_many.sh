@@ -7,7 +7,7 @@ for i in $(seq $R); do
     python - "$L" <<'PY'
 import json,sys
 d=json.load(open("gpurun_out/ab_tmp.json"))
-print(sys.argv[1].split("/")[-1], d["value"], d["roofline"]["kernels_ms"])
+print(sys.argv[1].split("/")[-1], d["value"], d["roofline"]["kernels_ms"], d["per_call_ms"])
 PY
   done
 done

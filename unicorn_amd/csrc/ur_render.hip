@@ -927,10 +927,11 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     hide_key = s_hide[lane];
     int n_rel = cnt;
     constexpr int kDeep = 8;
-    // lists longer than kDeep are first compacted against the hide key in place (they may live partly in the spill
-    // area); the short ones drop their hidden entries on the way through the register sort below
-    if (__any(hide_key != ~0ull && cnt > kDeep)) {
-      const bool need = hide_key != ~0ull && cnt > kDeep;
+    // Every list drops its hidden entries (behind the hide key) on the way through its sort below: they are replaced
+    // by the all-ones pad, which sorts to the end.  Only lists too long for a sorting network (more than 128 entries:
+    // K > 128) are compacted in place first.
+    if (BIGK && __any(hide_key != ~0ull && cnt > 128)) {
+      const bool need = hide_key != ~0ull && cnt > 128;
       const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(need ? cnt : 0));
       const int j = keys.compact(need, cnt, maxcnt, hide_key);
       if (need) n_rel = j;
@@ -1011,9 +1012,11 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
             if (sub == u) { myl = l; have = any; }
           }
           const int nl = __shfl(n_rel, myl, 64);  // every lane takes part: a masked-off lane cannot be read from
+          const unsigned long long hk = __shfl(hide_key, myl, 64);
           const int myn = have ? nl : 0;
           unsigned long long v = ~0ull;
           if (j < myn) v = (j < P.cap) ? lds_base[(size_t)j * 64 + myl] : spill_base[(size_t)(j - P.cap) * 64 + myl];
+          if (v > hk) v = ~0ull;  // hidden
 #pragma unroll
           for (int k = 2; k <= Wd; k <<= 1)
 #pragma unroll
@@ -1022,10 +1025,13 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
               const bool take_min = ((j & d) == 0) == ((j & k) == 0);
               v = (take_min == (o < v)) ? o : v;
             }
-          if (j < myn) {
+          const unsigned long long live = __ballot(v != ~0ull) >> (sub * Wd);
+          const int kept = __popcll(Wd == 64 ? live : (live & ((1ull << (Wd & 63)) - 1ull)));
+          if (j < kept) {
             if (j < P.cap) lds_base[(size_t)j * 64 + myl] = v;
             else spill_base[(size_t)(j - P.cap) * 64 + myl] = v;
           }
+          if (have && j == 0) s_cnt[myl] = kept;  // the list's new length, picked up by its pixel below
         }
       };
       const unsigned long long d16 = __ballot(n_rel > kDeep && n_rel <= 16), d32 = __ballot(n_rel > 16 && n_rel <= 32),
@@ -1041,23 +1047,27 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           const int l = __builtin_ctzll(d128);
           d128 &= d128 - 1;
           const int nl = __builtin_amdgcn_readlane(n_rel, l);
+          const unsigned long long hk =
+              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hide_key >> 32), l) << 32) |
+              (unsigned)__builtin_amdgcn_readlane((int)(unsigned)hide_key, l);
           unsigned long long v[2];
-  #pragma unroll
+#pragma unroll
           for (int r2 = 0; r2 < 2; ++r2) {
             const int e = lane + 64 * r2;
             v[r2] = ~0ull;
             if (e < nl) v[r2] = (e < P.cap) ? lds_base[(size_t)e * 64 + l] : spill_base[(size_t)(e - P.cap) * 64 + l];
+            if (v[r2] > hk) v[r2] = ~0ull;  // hidden
           }
-  #pragma unroll
+#pragma unroll
           for (int k = 2; k <= 128; k <<= 1)
-  #pragma unroll
+#pragma unroll
             for (int d = k >> 1; d > 0; d >>= 1) {
               if (d == 64) {
                 const bool sw = v[1] < v[0];
                 const unsigned long long lo = sw ? v[1] : v[0], hi = sw ? v[0] : v[1];
                 v[0] = lo; v[1] = hi;
               } else {
-  #pragma unroll
+#pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2) {
                   const int e = lane + 64 * r2;
                   const unsigned long long o = __shfl_xor(v[r2], d, 64);
@@ -1066,16 +1076,20 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 }
               }
             }
-  #pragma unroll
+#pragma unroll
           for (int r2 = 0; r2 < 2; ++r2) {
             const int e = lane + 64 * r2;
-            if (e < nl) {
+            if (v[r2] != ~0ull) {  // sorted: the kept entries come first
               if (e < P.cap) lds_base[(size_t)e * 64 + l] = v[r2];
               else spill_base[(size_t)(e - P.cap) * 64 + l] = v[r2];
             }
           }
+          const int kept = __popcll(__ballot(v[0] != ~0ull)) + __popcll(__ballot(v[1] != ~0ull));
+          if (lane == 0) s_cnt[l] = kept;
         }
       }
+      // the pixels whose lists went through a cross-lane sort pick up their new lengths
+      if (n_rel > kDeep && n_rel <= (BIGK ? 128 : 64)) n_rel = s_cnt[lane];
     }
     const int m = min(n_rel, K);  // layers of this pixel that matter, front to back in slots [0, m): the K nearest
     const int incl = wave_scan_add(m);
