@@ -189,11 +189,14 @@ def test_fused_equals_two_stage_bitwise_forward():
     assert torch.equal(a[1](a[2], a[3][2], a[3][3]), b[1](b[2], b[3][2], b[3][3]))
 
 
+@pytest.mark.parametrize("K,level,H", [(30, 2, 24), (100, 3, 24), (150, 3, 16)], ids=["K30", "K100", "K150"])
 @pytest.mark.parametrize("mode_kw", [dict(clip_inside=False), dict(clip_inside=True)], ids=["sigmoid", "clip"])
-def test_deep_translucent_stacks(mode_kw):
-    """wide soft edges: many translucent layers per pixel (more than the backward keeps in LDS at once)"""
-    sigma, K, H = 3e-2, 30, 24
-    sc, rend, meshes, (verts, maps, R, T) = _setup(2, 2, H, K, seed=13, sigma=sigma, **mode_kw)
+def test_deep_translucent_stacks(mode_kw, K, level, H):
+    """wide soft edges: many translucent layers per pixel (more than the backward keeps in LDS at once).  K30: lists
+    of up to 60 candidates cut to 30; K100: the K > 64 build, lists of 65..128 entries (two entries per lane in the
+    sort) that fill up; K150: lists longer than any sorting network (in-place compaction + per-lane selection sort)"""
+    sigma = 3e-2
+    sc, rend, meshes, (verts, maps, R, T) = _setup(2, level, H, K, seed=13, sigma=sigma, **mode_kw)
     out = rend(meshes, R, T)
     cot = np.random.RandomState(5).randn(*out.shape).astype(np.float32)
     (out * torch.from_numpy(cot).cuda()).sum().backward()
