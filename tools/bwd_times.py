@@ -51,3 +51,50 @@ if w.shape[1] > 9 and float(w[:, 9].sum()) > 0:  # dev counters of the timing bu
         items, float(w[:, 7].sum()), 100 * float(w[:, 7].sum()) / items, float(w[:, 8].sum()), 100 * float(w[:, 8].sum()) / (4 * items)))
     nb = torch.ceil(w[:, 9] / 64)
     print("phase B us per batch: %.2f" % (float(us(w[:, 3] - w[:, 2]).sum()) / float(nb.sum())))
+# the slowest waves, and whether a wave's duration follows its own work or its CU's (workgroup i runs on CU i mod 256)
+dur = us(w[:, 4] - w[:, 0])
+idx = torch.nonzero(live)[:, 0]
+hv = torch.argsort(dur, descending=True)[:12]
+for i in hv.tolist():
+    print("  slow wave: wg %d wave %d start %.1f A %.1f B %.1f flush %.1f whole %.1f ; depth %d items %d face-fb %d texel-fb %d" % (
+        int(idx[i]) // 4, int(idx[i]) % 4, float(us(w[i, 0] - t0)), float(us(w[i, 2] - w[i, 1])), float(us(w[i, 3] - w[i, 2])),
+        float(us(w[i, 4] - w[i, 3])), float(dur[i]), int(w[i, 6]), int(w[i, 9]) if w.shape[1] > 9 else -1,
+        int(w[i, 7]) if w.shape[1] > 9 else -1, int(w[i, 8]) if w.shape[1] > 9 else -1))
+if w.shape[1] > 9:
+    def corr(a, b):
+        a = a - a.mean(); b = b - b.mean()
+        return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+    print("corr(wave items, phase B) %.3f ; corr(wave items, whole) %.3f ; corr(depth, phase A) %.3f" % (
+        corr(w[:, 9], us(w[:, 3] - w[:, 2])), corr(w[:, 9], dur), corr(w[:, 6], us(w[:, 2] - w[:, 1]))))
+    # per workgroup: end time and items; per CU (first 1024 workgroups, all resident from the start)
+    wg = (idx // 4)
+    nwg = nblk
+    end_wg = torch.zeros(nwg, dtype=torch.double); items_wg = torch.zeros(nwg, dtype=torch.double)
+    end_wg.scatter_reduce_(0, wg, us(w[:, 4] - t0), reduce="amax"); items_wg.scatter_add_(0, wg, w[:, 9])
+    first = torch.arange(min(1024, nwg))
+    cu = first % 256
+    cu_end = torch.zeros(256, dtype=torch.double).scatter_reduce_(0, cu, end_wg[first], reduce="amax")
+    cu_items = torch.zeros(256, dtype=torch.double).scatter_add_(0, cu, items_wg[first])
+    print("per workgroup: items min %.0f mean %.0f max %.0f ; corr(items, end) %.3f" % (float(items_wg[first].min()), float(items_wg[first].mean()), float(items_wg[first].max()), corr(items_wg[first], end_wg[first])))
+    print("per CU: end min %.1f mean %.1f max %.1f ; items min %.0f mean %.0f max %.0f ; corr(CU items, CU end) %.3f" % (
+        float(cu_end.min()), float(cu_end.mean()), float(cu_end.max()), float(cu_items.min()), float(cu_items.mean()), float(cu_items.max()), corr(cu_items, cu_end)))
+if w.shape[1] > 10 and float(w[:, 10].sum()) > 0:  # physical placement (HW_ID: cu 11:8, sh 12, se 15:13; XCC_ID)
+    raw = tim.view(nblk * 4, 16).cpu()[live][:, 10]
+    hw = raw & 0xffffffff; xcc = raw >> 32
+    phys = (xcc * 8 + ((hw >> 13) & 7)) * 32 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15)
+    uniq, inv = torch.unique(phys, return_inverse=True)
+    n_cu = uniq.numel()
+    end = torch.zeros(n_cu, dtype=torch.double).scatter_reduce_(0, inv, us(w[:, 4] - t0), reduce="amax")
+    itm = torch.zeros(n_cu, dtype=torch.double).scatter_add_(0, inv, w[:, 9])
+    nwv = torch.zeros(n_cu, dtype=torch.double).scatter_add_(0, inv, torch.ones_like(dur))
+    print("physical CUs seen %d ; waves per CU min %d max %d ; items per CU min %.0f mean %.0f max %.0f ; end min %.1f mean %.1f max %.1f ; corr(items, end) %.3f ; corr(waves, end) %.3f" % (
+        n_cu, int(nwv.min()), int(nwv.max()), float(itm.min()), float(itm.mean()), float(itm.max()), float(end.min()), float(end.mean()), float(end.max()), corr(itm, end), corr(nwv, end)))
+    same = 0
+    for c in range(256):
+        sel = (idx // 4) % 256 == c
+        sel &= (idx // 4) < 1024
+        if sel.any() and torch.unique(phys[sel]).numel() == 1: same += 1
+    print("launch columns (wg mod 256, first 1024 wgs) that sit on ONE physical CU: %d of 256" % same)
+    top = torch.argsort(end, descending=True)[:8]
+    for c in top.tolist():
+        print("  late CU: xcc %d se %d sh %d cu %d : end %.1f items %.0f waves %d ; wgs %s" % (int(uniq[c]) // 256, (int(uniq[c]) // 32) % 8, (int(uniq[c]) // 16) % 2, int(uniq[c]) % 16, float(end[c]), float(itm[c]), int(nwv[c]), sorted(set((idx[inv == c] // 4).tolist()))[:8]))
