@@ -381,6 +381,8 @@ struct RasterParams {
   const float* fz;  // nearest corner depth per face
   const int64_t* nfaces;
   int N, H, W, K;
+  int eqF;  // > 0: every mesh has eqF faces and mesh n starts at n * eqF (the one-call path) -- saves the kernels a
+            // dependent load of first[n] / nfaces[n] before their first useful one
   float blur;
   int clip;
   int nbx, nby;  // bins per row / column
@@ -421,7 +423,7 @@ struct RasterParams {
 
 // face-UV table row of packed face `fid` of mesh n
 __device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n, int fid) {
-  const int64_t fl = P.fuv_shared ? (int64_t)fid - P.first[n] : (int64_t)fid;
+  const int64_t fl = P.fuv_shared ? (int64_t)fid - (P.eqF > 0 ? (int64_t)n * P.eqF : P.first[n]) : (int64_t)fid;
   return P.fuv + fl * 6;
 }
 
@@ -573,8 +575,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     }
   }
 
-  const int64_t f0 = P.first[n];
-  const int nf = (int)P.nfaces[n];
+  const int64_t f0 = P.eqF > 0 ? (int64_t)n * P.eqF : P.first[n];
+  const int nf = P.eqF > 0 ? P.eqF : (int)P.nfaces[n];
 
   for (int rbase = 0; rbase < nf; rbase += kBinCap) {
     // ---- coarse: the round's faces (up to 2048) are split evenly over the waves, wave w scans a contiguous range
@@ -2643,6 +2645,7 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
                               face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
   if (rc) return rc;
   if (N == 0) return UR_OK;
+  P.eqF = F;
   hipStream_t st = (hipStream_t)stream;
   const int nbins = ((H + 15) / 16) * ((W + 15) / 16);
   const int64_t n_gfv = (int64_t)F * 9, n_gmap = (int64_t)Ht * Wt * 3;
