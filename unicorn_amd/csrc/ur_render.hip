@@ -541,6 +541,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   keys.lds = s_keys_all + (size_t)wave * P.cap * 64 + lane;
   keys.spill = P.spill + (tile_live ? tile_id : 0) * (int64_t)(KL - P.cap) * 64 + lane;
   int cnt = 0;       // entries in this lane's list
+  // BIGK, list full: the two largest entries found by the last scan of the list (full_known = how many of them still
+  // hold: 2 after a scan, 1 after one replacement, 0 = scan again); any compaction or append resets it
+  unsigned long long full_m1 = 0, full_m2 = 0;
+  int full_i1 = 0, full_i2 = 0, full_known = 0;
   int tl_count = 0;  // MODE 1: faces appended to this tile's list (wave-uniform)
   // MODE 2 only: depth of the nearest hit found so far that hides everything behind it (alpha == 1 and
   // d(alpha)/d(dist) == 0).  A face whose nearest corner lies behind it cannot matter to this pixel's blend: its
@@ -705,27 +709,49 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           }
           cnt = j;
           stale = false;
+          full_known = 0;
         }
         if (MODE == 2 && key > hide_key) {
           // behind a hit that hides the rest: irrelevant to the blend
         } else if (cnt < KL) {
           keys.put(cnt, key);
           ++cnt;
+          full_known = 0;
         } else {
-          // list full: the newcomer replaces the current maximum when it is smaller (rare path)
-          unsigned long long mx = 0;
-          int im = 0;
+          // list full: the newcomer replaces the current maximum when it is smaller
           if constexpr (BIGK) {
-            // most of a long list sits in the global spill area: read eight entries at a time
-            for (int i0 = 0; i0 < KL; i0 += 8) {
-              unsigned long long t[8];
+            // Most of a long list sits in the global spill area, so a scan is dear (eight entries in flight at a
+            // time) and full lists come in numbers (silhouette bins of dense meshes): a scan keeps the TWO largest
+            // entries, which settles every newcomer that is no improvement and one replacement without another scan.
+            if (full_known == 0) {
+              unsigned long long m1 = 0, m2 = 0;
+              int i1 = 0, i2 = 0;
+              for (int i0 = 0; i0 < KL; i0 += 8) {
+                unsigned long long t[8];
 #pragma unroll
-              for (int q = 0; q < 8; ++q) t[q] = (i0 + q < KL) ? keys.get(i0 + q) : 0ull;
+                for (int q = 0; q < 8; ++q) t[q] = (i0 + q < KL) ? keys.get(i0 + q) : 0ull;
 #pragma unroll
-              for (int q = 0; q < 8; ++q)
-                if (t[q] > mx) { mx = t[q]; im = i0 + q; }
+                for (int q = 0; q < 8; ++q) {
+                  if (t[q] > m1) { m2 = m1; i2 = i1; m1 = t[q]; i1 = i0 + q; }
+                  else if (t[q] > m2) { m2 = t[q]; i2 = i0 + q; }
+                }
+              }
+              full_m1 = m1; full_i1 = i1; full_m2 = m2; full_i2 = i2;
+              full_known = 2;
+            }
+            if (key < full_m1) {
+              keys.put(full_i1, key);
+              if (full_known == 2) {  // the new maximum: the runner-up, or the newcomer where it sits
+                if (key > full_m2) full_m1 = key;
+                else { full_m1 = full_m2; full_i1 = full_i2; }
+                full_known = 1;
+              } else {
+                full_known = 0;
+              }
             }
           } else {
+            unsigned long long mx = 0;
+            int im = 0;
             for (int i0 = 0; i0 < KL; i0 += 4) {
               unsigned long long t[4];
 #pragma unroll
@@ -734,8 +760,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
               for (int q = 0; q < 4; ++q)
                 if (t[q] > mx) { mx = t[q]; im = i0 + q; }
             }
+            if (key < mx) keys.put(im, key);
           }
-          if (key < mx) keys.put(im, key);
         }
       }
     };
@@ -829,6 +855,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 const bool need = (hk != last_hk) && c2 > 0;
                 const int mx = __builtin_amdgcn_readfirstlane(wave_max(need ? c2 : 0));
                 const int j = keys.compact(need, c2, mx, hk);
+                full_known = 0;
                 if (need) { c2 = j; s_cnt[lane] = c2; }
                 last_hk = hk;
                 any_stale = false;
