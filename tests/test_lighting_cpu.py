@@ -6,7 +6,7 @@ import torch
 
 from unicorn_amd import lighting, synth
 from unicorn_amd.renderer import DirectionalLights, PointLights, AmbientLights, Fragments
-from unicorn_amd.structures import Meshes, TexturesUV
+from unicorn_amd.structures import Meshes, TexturesUV, TexturesVertex
 
 
 def _norm(v, eps=1e-6):
@@ -86,3 +86,25 @@ def test_camera_center_inverts_the_view_transform():
     R, T = sc["R"], sc["T"]
     c = lighting.camera_center(R, T)
     np.testing.assert_allclose((torch.bmm(c[:, None], R)[:, 0] + T).numpy(), 0.0, atol=1e-5)
+
+
+def test_gouraud_shading_matches_numpy():
+    """lighting at the vertices (vertex colours x (ambient + diffuse) + specular), then barycentric interpolation
+    (renderer.py:140-141,169)"""
+    sc, meshes, frag, p2f, bary = _scene(seed=3)
+    N, V = sc["verts"].shape[:2]
+    vcol = torch.rand(N, V, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    meshes.textures = TexturesVertex(vcol)
+    R, T = sc["R"].double(), sc["T"].double()
+    cam = (-(T[:, None] @ R.transpose(1, 2))[:, 0]).numpy()
+    v, f = meshes.verts_packed().numpy(), meshes.faces_packed().numpy()
+    vn = meshes.verts_normals_packed().numpy()
+    mask = (p2f >= 0)[..., None]
+    idx = np.maximum(p2f, 0)
+    for lights in (DirectionalLights(direction=((0.3, -0.2, -1.0),)), PointLights(location=((0.5, 1.0, -2.0),)),
+                   AmbientLights(ambient_color=((0.7, 0.8, 0.9),))):
+        amb, dif, spe = _np_light(v, vn, np.repeat(cam, V, 0), lights)
+        lit = vcol.numpy().reshape(-1, 3) * (amb + dif) + spe
+        want = (bary[..., None] * lit[f][idx]).sum(-2) * mask
+        got = lighting.gouraud_shading(meshes, frag, lights, lighting.Materials(), R, T).numpy()
+        np.testing.assert_allclose(got, want, atol=1e-6)

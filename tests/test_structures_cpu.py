@@ -1,0 +1,159 @@
+"""The `Meshes` / texture / camera surface the reference's callers use, on the CPU: plain tensor
+bookkeeping, no kernels.  Call sites: unicorn.py:92-93 (scale_verts, get_mesh_verts_faces), :262-266 (extend,
+offset_verts_, scale_verts_), :389,407 (`meshes[i]`-style indexing and detach in the neighbour swap), :499
+(offset_verts), :512-513 (extend); utils/mesh.py:21-71 (normalize, repeat); renderer.py:247 (look_at_view_transform);
+kp_eval.py:91-104 (transform_points_screen)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from unicorn_amd import synth
+from unicorn_amd.cameras import FoVPerspectiveCameras, PerspectiveCameras, look_at_view_transform
+from unicorn_amd.structures import Meshes, TexturesUV, TexturesVertex, join_meshes_as_batch, repeat
+
+
+def _template(level=1):
+    v, f = synth.icosphere(level)
+    return Meshes(v[None], f[None])
+
+
+def test_predict_meshes_call_sequence():
+    """unicorn.py:262-266: template.extend(B); offset_verts_(packed displacements); textures set; scale_verts_((B,3))"""
+    tmpl = _template().scale_verts(torch.tensor([[1.0, 0.7, 0.7]]) * 0.6)  # unicorn.py:88-92: (1,3) scale
+    verts, faces = tmpl.get_mesh_verts_faces(0)
+    V, B = verts.shape[0], 4
+    assert torch.allclose(verts, synth.icosphere(1)[0] * torch.tensor([0.6, 0.42, 0.42]))
+    g = torch.Generator().manual_seed(0)
+    disp = torch.randn(B * V, 3, generator=g, requires_grad=True)
+    scales = (1 + 0.1 * torch.randn(B, 3, generator=g)).requires_grad_(True)
+    meshes = tmpl.extend(B)
+    assert len(meshes) == B and meshes.verts_padded().shape == (B, V, 3)
+    ret = meshes.offset_verts_(disp)
+    assert ret is meshes  # in place, like pytorch3d
+    maps = torch.rand(B, 8, 8, 3, generator=g)
+    uvs = synth.spherical_uvs(verts)[None]
+    meshes.textures = TexturesUV(maps, faces[None].expand(B, -1, -1), uvs.expand(B, -1, -1))
+    meshes.scale_verts_(scales)
+    want = (verts[None] + disp.view(B, V, 3)) * scales[:, None]
+    assert torch.allclose(meshes.verts_padded(), want)
+    assert torch.equal(meshes.verts_packed(), meshes.verts_padded().reshape(-1, 3))
+    meshes.verts_padded().sum().backward()  # autograd reaches both predictions
+    assert disp.grad is not None and scales.grad is not None and scales.grad.shape == (B, 3)
+    # faces_packed offsets every mesh's indices by its first vertex
+    fp = meshes.faces_packed()
+    assert fp.shape == (B * faces.shape[0], 3) and int(fp.max()) == B * V - 1
+    assert torch.equal(fp[faces.shape[0]:2 * faces.shape[0]], faces + V)
+    assert torch.equal(meshes.num_verts_per_mesh(), torch.full((B,), V))
+    assert torch.equal(meshes.verts_packed_to_mesh_idx(), torch.arange(B).repeat_interleave(V))
+
+
+def test_offset_verts_returns_a_new_mesh_and_accepts_a_vector():
+    tmpl = _template()
+    V = tmpl.verts_packed().shape[0]
+    moved = tmpl.offset_verts(torch.ones(V, 3))  # unicorn.py:499
+    assert moved is not tmpl and torch.allclose(moved.verts_packed(), tmpl.verts_packed() + 1)
+    assert torch.allclose(tmpl.offset_verts(torch.tensor([1.0, 2.0, 3.0])).verts_packed(),
+                          tmpl.verts_packed() + torch.tensor([1.0, 2.0, 3.0]))
+    assert torch.allclose(tmpl.scale_verts(2.0).verts_packed(), 2 * tmpl.verts_packed())
+
+
+def test_extend_is_repeat_interleave_and_repeat_is_tile():
+    """pytorch3d extend: (m0, m0, m1, m1); the reference's repeat (utils/mesh.py:43-71): (m0, m1, m0, m1)"""
+    v, f = synth.icosphere(1)
+    verts = torch.stack([v, 2 * v, 3 * v])
+    tex = TexturesVertex(torch.stack([torch.full_like(v, c) for c in (0.1, 0.2, 0.3)]))
+    m = Meshes(verts, f[None].expand(3, -1, -1), tex)
+    e, r = m.extend(2), repeat(m, 2)
+    scale = lambda mm: [round(float(x.abs().max() / v.abs().max())) for x in mm.verts_list()]
+    assert scale(e) == [1, 1, 2, 2, 3, 3] and scale(r) == [1, 2, 3, 1, 2, 3]
+    assert [round(float(t[0, 0]), 1) for t in e.textures.verts_features_padded()] == [0.1, 0.1, 0.2, 0.2, 0.3, 0.3]
+    assert [round(float(t[0, 0]), 1) for t in r.textures.verts_features_padded()] == [0.1, 0.2, 0.3, 0.1, 0.2, 0.3]
+    assert repeat(m, 1) is m
+
+
+def test_indexing_detach_and_list_built_meshes():
+    v, f = synth.icosphere(1)
+    verts = [v.clone().requires_grad_(True), (2 * v).requires_grad_(True), (3 * v).requires_grad_(True)]
+    maps = torch.rand(3, 4, 4, 3, requires_grad=True)
+    uvs = synth.spherical_uvs(v)
+    m = Meshes(verts, [f.clone() for _ in range(3)], TexturesUV(maps, f[None].repeat(3, 1, 1), uvs[None].repeat(3, 1, 1)))
+    assert m.equisized and len(m) == 3 and not m.isempty()
+    one = m[1]
+    assert len(one) == 1 and torch.equal(one.verts_padded()[0], verts[1]) and one.textures.maps_padded().shape[0] == 1
+    sub = m[[2, 0]]
+    assert torch.equal(sub.verts_list()[0], verts[2]) and torch.equal(sub.textures.maps_padded()[1], maps[0])
+    assert torch.equal(m[torch.tensor([True, False, True])].verts_list()[1], verts[2])
+    assert len(m[1:]) == 2
+    d = m.detach()
+    assert not d.verts_padded().requires_grad and not d.textures.maps_padded().requires_grad
+    assert m.verts_padded().requires_grad and torch.equal(d.verts_padded(), m.verts_padded())
+    vv, ff = m.get_mesh_verts_faces(2)
+    assert vv is verts[2] and torch.equal(ff, f)
+    j = join_meshes_as_batch([m[0], m[2]])
+    assert len(j) == 2 and torch.equal(j.verts_list()[1], verts[2])
+    # heterogeneous batch: not equisized, packed views still consistent
+    v2, f2 = synth.icosphere(2)
+    h = Meshes([v, v2], [f, f2])
+    assert not h.equisized and h.verts_packed().shape[0] == v.shape[0] + v2.shape[0]
+    assert torch.equal(h.faces_packed()[f.shape[0]:], f2 + v.shape[0])
+    assert torch.equal(h.mesh_to_faces_packed_first_idx(), torch.tensor([0, f.shape[0]]))
+
+
+def test_edges_of_a_closed_mesh():
+    """edges_packed / faces_packed_to_edges_packed feed normal_consistency (utils/mesh.py:92-139)"""
+    m = _template(2)
+    V, F = m.verts_packed().shape[0], m.faces_packed().shape[0]
+    e, f2e = m.edges_packed(), m.faces_packed_to_edges_packed()
+    assert e.shape == (3 * F // 2, 2) and V - e.shape[0] + F == 2  # Euler
+    assert (e[:, 0] < e[:, 1]).all() and f2e.shape == (F, 3)
+    faces = m.faces_packed()
+    for i, (a, b) in enumerate([(1, 2), (2, 0), (0, 1)]):  # edge i is opposite to corner i
+        got = e[f2e[:, i]]
+        want = torch.stack([faces[:, a], faces[:, b]], 1).sort(1).values
+        assert torch.equal(got, want)
+    assert torch.bincount(f2e.flatten()).eq(2).all()  # every edge has exactly two faces
+
+
+def test_look_at_view_transform():
+    """renderer.py:247: turntable cameras.  R is orthonormal with det +1, the camera sits at distance `dist` from the
+    origin, looks at it (the origin projects to view (0, 0, dist)) and keeps +Y up."""
+    azim = torch.linspace(-180, 180, 9)
+    R, T = look_at_view_transform(dist=2.5, elev=30.0, azim=azim)
+    assert R.shape == (9, 3, 3) and T.shape == (9, 3)
+    eye = torch.eye(3).expand(9, 3, 3)
+    assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-5) and torch.allclose(torch.det(R), torch.ones(9), atol=1e-5)
+    assert torch.allclose(T, torch.tensor([0.0, 0.0, 2.5]).expand(9, 3), atol=1e-5)  # origin -> (0, 0, dist)
+    C = -torch.bmm(T[:, None], R.transpose(1, 2))[:, 0]  # camera centre in the world
+    el, az = math.radians(30.0), azim * math.pi / 180
+    want = 2.5 * torch.stack([math.cos(el) * torch.sin(az), torch.full_like(az, math.sin(el)), math.cos(el) * torch.cos(az)], -1)
+    assert torch.allclose(C, want, atol=1e-5)
+    up_view = torch.tensor([0.0, 1.0, 0.0]) @ R  # world +Y seen from the camera: positive y, no x component
+    assert (up_view[:, 1] > 0.5).all() and torch.allclose(up_view[:, 0], torch.zeros(9), atol=1e-6)
+    # straight down the up axis: still a proper rotation
+    R2, _ = look_at_view_transform(dist=1.0, elev=90.0, azim=0.0)
+    assert torch.allclose(R2 @ R2.transpose(1, 2), torch.eye(3)[None], atol=1e-4)
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 80), (80, 48)])
+def test_transform_points_screen_inverts_the_pixel_centre_map(H, W):
+    """screen (x, y) of a point = (column, row) of the pixel whose centre it projects to, for the rasterizer's map
+    x_ndc = r_x (1 - (2 col + 1) / W), r_x = max(W / H, 1) (oracle: pix_to_ndc), on both camera classes"""
+    s = 1.0 / math.tan(math.radians(15.0))
+    for cam in (FoVPerspectiveCameras(fov=30.0), PerspectiveCameras(focal_length=s)):
+        cols, rows = torch.meshgrid(torch.arange(0, W, 7.0), torch.arange(0, H, 5.0), indexing="xy")
+        x_ndc = max(W / H, 1.0) * (1 - (2 * cols + 1) / W)
+        y_ndc = max(H / W, 1.0) * (1 - (2 * rows + 1) / H)
+        z = torch.full_like(x_ndc, 3.0)
+        pts = torch.stack([x_ndc * z / s, y_ndc * z / s, z], -1).reshape(1, -1, 3)
+        scr = cam.transform_points_screen(pts, image_size=(H, W))
+        assert torch.allclose(scr[0, :, 0], cols.flatten(), atol=1e-3)
+        assert torch.allclose(scr[0, :, 1], rows.flatten(), atol=1e-3)
+        assert torch.allclose(scr[0, :, 2], z.flatten())
+        # with a camera pose: same answer for the world points that map to those view points
+        R = synth.pose_to_R(torch.tensor([40.0]), torch.tensor([10.0]), torch.tensor([5.0]))
+        T = torch.tensor([[0.1, -0.2, 2.7]])
+        world = (pts - T[:, None]) @ R.transpose(1, 2)
+        scr2 = cam.transform_points_screen(world, image_size=((H, W),), R=R, T=T)
+        assert torch.allclose(scr2, scr, atol=2e-3)

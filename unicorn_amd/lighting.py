@@ -3,7 +3,7 @@
 (renderer.py:225-234).  The light models restate the reference's own `diffuse` / `specular`
 (pytorch3d_monkey.py:73-198) and `_apply_lighting` (:34-70); the shading functions restate pytorch3d 0.6.2's
 phong_shading / gouraud_shading / flat_shading (third-party, absent here: parity unpinned, checked against a numpy
-restatement in tests/test_gpu_lighting.py).
+restatement in tests/test_lighting_cpu.py, gouraud end to end in tests/test_gpu_vertex_textures.py).
 
 Plain differentiable torch ops on the fragments the HIP rasterizer produced: this is per-fragment arithmetic on a
 visualisation path, the blending that follows is a HIP kernel (ur_blend_colors)."""

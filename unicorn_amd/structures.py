@@ -116,6 +116,9 @@ class TexturesVertex:
     def verts_features_packed(self):
         return self._feat.reshape(-1, self._feat.shape[-1])
 
+    def verts_features_list(self):
+        return list(self._feat.unbind(0))
+
     def detach(self):
         return TexturesVertex(self._feat.detach())
 
