@@ -96,6 +96,22 @@ int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face,
                         float* bary, float* dists, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * ur_rasterize_meshes without any allocation on anybody's side: no counterpart in the reference.  For callers that
+ * cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc -- and therefore cannot provide the workspace either.  Same arguments, kernels and results (bit for bit) as
+ * ur_rasterize_meshes, minus workspace / workspace_bytes: the face records, the bin schedule and the K-list spill live
+ * in a static device array of UR_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process
+ * ends.  A call that would need more (ur_workspace_bytes(total_faces, N, H, W, K) > UR_STATIC_SCRATCH_BYTES) returns
+ * UR_ERR_WORKSPACE and launches nothing.  Calls no hipMalloc / hipFree.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads) race; serialise them.
+ */
+#define UR_STATIC_SCRATCH_BYTES (64u << 20)
+int ur_rasterize_meshes_static(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces,
+                               int N, int64_t total_faces, int H, int W, float blur_radius, int K,
+                               int perspective_correct, int clip_barycentric_coords, int cull_backfaces,
+                               int32_t* pix_to_face, float* zbuf, float* bary, float* dists, void* stream);
+
+/*
  * Replaces: pytorch3d._C.rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists,
  *           perspective_correct, clip_barycentric_coords) -> grad_face_verts (NF,3,3), reached from trainer.py:151.
  * grad_face_verts must be zero-filled by the caller.  Any of grad_zbuf / grad_bary / grad_dists may be NULL (= zeros).

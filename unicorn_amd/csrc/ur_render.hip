@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -29,6 +30,11 @@
 using namespace ur;
 
 extern "C" size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K);
+
+// Device memory of the allocation-free entry point (ur_rasterize_meshes_static): one copy per GPU, held from module
+// load to process exit.  In host code this name is only a handle for hipGetSymbolAddress -- kernels and memsets are
+// given the per-device address kept in g_scratch_ptr, never the name.
+static __device__ __align__(256) unsigned char scratch[UR_STATIC_SCRATCH_BYTES];
 
 namespace {
 
@@ -67,6 +73,24 @@ struct ProfScope {  // records the slot's events around a kernel launch when pro
     if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
   }
 };
+
+// per-device address of `scratch`, looked up once per device with that device current
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[64] = {};
+
+int static_scratch(void** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(UR_ERR_LAUNCH, "no current device");
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) return fail(UR_ERR_LAUNCH, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return UR_OK;
+}
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -2446,6 +2470,25 @@ int ur_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face,
   P.N = N; P.H = H; P.W = W; P.K = K; P.blur = blur_radius; P.clip = clip_barycentric_coords;
   P.p2f = pix_to_face; P.zbuf = zbuf; P.bary = bary; P.dists = dists;
   return launch_raster<0>(P, st);
+}
+
+int ur_rasterize_meshes_static(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces,
+                               int N, int64_t total_faces, int H, int W, float blur_radius, int K,
+                               int perspective_correct, int clip_barycentric_coords, int cull_backfaces,
+                               int32_t* pix_to_face, float* zbuf, float* bary, float* dists, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0 || total_faces < 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  const size_t need = ur_workspace_bytes(total_faces, N, H, W, K);
+  if (need > (size_t)UR_STATIC_SCRATCH_BYTES)
+    return fail(UR_ERR_WORKSPACE,
+                "this call needs %zu bytes of scratch but the static scratch holds %zu: use ur_rasterize_meshes with a "
+                "caller-allocated workspace", need, (size_t)UR_STATIC_SCRATCH_BYTES);
+  void* ptr = nullptr;
+  if (int rc = static_scratch(&ptr)) return rc;
+  // same kernels as ur_rasterize_meshes; the bin-load counters inside the scratch are cleared by the call itself
+  // (hipMemsetAsync on `ptr`), everything else in it is written before it is read
+  return ur_rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, N, total_faces, H, W, blur_radius, K,
+                             perspective_correct, clip_barycentric_coords, cull_backfaces, pix_to_face, zbuf, bary,
+                             dists, ptr, (size_t)UR_STATIC_SCRATCH_BYTES, stream);
 }
 
 int ur_tile_faces(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int N,

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "ur_project_faces_backward": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ur_rasterize_meshes": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                  _vp]),
+    "ur_rasterize_meshes_static": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ur_rasterize_meshes_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "ur_tile_faces": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ur_shade_blend": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
@@ -205,6 +206,30 @@ def rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, bl
                                          _ptr(dists, None, True), _ptr(ws), ws.numel(), _stream(face_verts)),
                "ur_rasterize_meshes")
     return p2f, zbuf, bary, dists
+
+
+STATIC_SCRATCH_BYTES = 64 << 20  # UR_STATIC_SCRATCH_BYTES
+
+
+def rasterize_meshes_static(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_radius, faces_per_pixel,
+                            clip_barycentric_coords, out, cull_backfaces=False, perspective_correct=False):
+    """ur_rasterize_meshes_static: the allocation-free variant.  `out` = (pix_to_face i32, zbuf, bary, dists), tensors
+    the CALLER holds ((N,H,W,K[,3]); any of the last three may be None); nothing is allocated here or in the library."""
+    H, W = image_size
+    N, K, NF = int(mesh_first_face.shape[0]), int(faces_per_pixel), int(face_verts.shape[0])
+    p2f, zbuf, bary, dists = out
+    for t, shape in ((p2f, (N, H, W, K)), (zbuf, (N, H, W, K)), (bary, (N, H, W, K, 3)), (dists, (N, H, W, K))):
+        if t is not None and tuple(t.shape) != shape:
+            raise ValueError(f"output tensor has shape {tuple(t.shape)}, expected {shape}")
+    with _on(face_verts):
+        _check(lib().ur_rasterize_meshes_static(_ptr(face_verts, torch.float32), _ptr(mesh_first_face, torch.int64),
+                                                _ptr(mesh_num_faces, torch.int64), N, NF, H, W, float(blur_radius), K,
+                                                int(perspective_correct), int(clip_barycentric_coords),
+                                                int(cull_backfaces), _ptr(p2f, torch.int32),
+                                                _ptr(zbuf, torch.float32, True), _ptr(bary, torch.float32, True),
+                                                _ptr(dists, torch.float32, True), _stream(face_verts)),
+               "ur_rasterize_meshes_static")
+    return out
 
 
 def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, clip_barycentric_coords,
