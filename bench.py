@@ -6,12 +6,23 @@ vertices, textures, R and T.  One "step" = one Renderer.forward + one backward o
 before the timed region.  With N>1 GPUs every rank renders its own batch (weak scaling, no collective on the data
 path -- images are independent); the timed region is bracketed by barrier + synchronize and the max over ranks is used.
 
-Prints ONE JSON line.  `roofline` prices the dominant kernel (the rasterizer launch) against HBM; `cpu_baseline` times
-the oracle's CPU restatement (oracle/, test infrastructure) on the host cores for a bounded sample of the same workload.
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts its own N ranks (a child
+`python -m torch.distributed.run`, the reference's trainer.py:284-290 spawns its ranks from the entry script too); under
+an external torch.distributed.run it just joins.  On a box with fewer GPUs than ranks the ranks share the GPUs over
+gloo (a rehearsal of the launch path; the line says so).
+
+Prints ONE JSON line.  `roofline` prices the dominant kernel against the bound the counters show -- VALU issue: these
+kernels are per-pixel geometry tests, sorting and scatter, not streaming -- with the kernel time measured
+live (HIP events on the launch stream) and the per-launch counter values from the committed rocprofv3 --pmc passes
+(profiles/r02_counters.json; counters cannot be read from inside the process); `path_hbm` keeps SURVEY 8(d)'s
+byte model beside it; `cpu_baseline` times the oracle's CPU restatement (oracle/, test infrastructure) on the host cores
+for a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +38,11 @@ from unicorn_amd.renderer import Renderer  # noqa: E402
 from unicorn_amd.structures import Meshes, TexturesUV  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
+# VALU issue roof: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 clocks per SIMD (16 lanes wide), 2.4 GHz nominal
+# shader clock (MI355X_MICROARCH.md; the chip runs lower under load, so the fraction is if anything understated)
+SIMDS, CLOCK_GHZ, CLK_PER_WAVE_VALU = 1024, 2.4, 4
+VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / CLK_PER_WAVE_VALU  # 614.4 G wave-instructions / s
+COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 WORKLOADS = {
     # name: batch per GPU, icosphere level, image, K, texture
@@ -84,6 +100,37 @@ def cpu_baseline(cfg, seconds_budget=12.0):
                       f"(pytorch3d itself is not available offline)"}
 
 
+def launch_own_ranks(n):
+    """`python bench.py --gpus N` started directly: run the N ranks as a child torch.distributed.run and pass its exit
+    code on.  Nothing here touches the GPU (device_count() does not initialise it on this image)."""
+    env = dict(os.environ)
+    if torch.cuda.device_count() < n:
+        env["UNICORN_BENCH_BACKEND"] = "gloo"  # fewer GPUs than ranks: the ranks share them (rehearsal)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_roofline(name, ms, counters, alg_bytes):
+    """one kernel against the VALU-issue roof (and its measured HBM traffic against the HBM roof).  `counters`: mean
+    per launch from rocprofv3 --pmc (SQ_INSTS_VALU in wave-instructions; FETCH_SIZE / WRITE_SIZE in KB)."""
+    out = {"kernel": name, "kernel_ms": round(ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+           "algorithmic_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1)}
+    if counters and "SQ_INSTS_VALU" in counters:
+        ginstr = counters["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
+        out.update(valu_wave_instructions=int(counters["SQ_INSTS_VALU"]), valu_Ginstr_per_s=round(ginstr, 1),
+                   valu_issue_frac=round(ginstr / VALU_PEAK_GINSTR, 4))
+    if counters and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        # gfx950: FETCH_SIZE tallies half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)
+        traffic = int((2 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
+        out.update(traffic=traffic, traffic_GBps=round(traffic / (ms * 1e-3) / 1e9, 1),
+                   hbm_frac=round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +143,8 @@ def main():
     ap.add_argument("--grads", default="verts+texture+R+T", help="which inputs require grad (ablation only; the "
                     "reported metric uses the default = all of them)")
     a = ap.parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_own_ranks(a.gpus))
 
     rank, local, world = udist.env_world()
     # rehearsal on a box with fewer GPUs than ranks: UNICORN_BENCH_BACKEND=gloo lets the ranks share a device
@@ -149,6 +198,9 @@ def main():
             launch = "hipGraph replay of one captured Renderer forward + backward"
         except Exception as e:  # capture unsupported: fall back, and say so in the result
             launch = f"eager (graph capture failed: {type(e).__name__}: {e})"[:200]
+    # every rank's own rate and a one-tensor all-reduce (RCCL under "nccl") that proves `world` ranks took part
+    per_rank = udist.gather_floats(B * a.steps / udist.last_local_elapsed(), world, cuda=True)
+    n_ranks_seen = udist.sum_over_ranks(1.0, world, cuda=True)
     # roofline leg (rank 0 only): the same steps again, eagerly, with (i) HIP events recorded by the library on the
     # launch stream right around the two dominant kernels (ur_profile_begin/end) and (ii) events around every C-ABI call
     result = None
@@ -162,16 +214,14 @@ def main():
         per_call = native.timing_summary()
         native.enable_timing(False)
         dom = max(kernel_ms, key=kernel_ms.get)  # the dominant kernel: k_raster<2> (fused forward)
-        dom_call = {"k_raster<2>": "ur_render_meshes_forward", "k_render_bwd": "ur_render_meshes_backward"}[dom]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):  # PMC counters cannot be read from inside the process: last committed measurement
-            tj = json.load(open(tpath))
-            if tj.get("workload") == a.workload and dom in tj:
-                traffic = int((2 * tj[dom]["FETCH_SIZE"] + tj[dom]["WRITE_SIZE"]) * 1024)
-        raster_ms = kernel_ms[dom]
-        alg = B * kernel_bytes_per_image(dom_call, H, H, K, F, cfg["tex"], cfg["tex"])
-        achieved = alg / (raster_ms * 1e-3) / 1e9
+        calls = {"k_raster<2>": "ur_render_meshes_forward", "k_render_bwd": "ur_render_meshes_backward"}
+        counters = {}
+        if os.path.exists(COUNTERS):  # PMC counters cannot be read from inside the process: last committed passes
+            counters = json.load(open(COUNTERS)).get("workloads", {}).get(a.workload, {})
+        roofs = {k: kernel_roofline(k, ms, counters.get(k), B * kernel_bytes_per_image(calls[k], H, H, K, F, cfg["tex"],
+                                                                                       cfg["tex"]))
+                 for k, ms in kernel_ms.items() if k in calls}
+        rd = roofs[dom]
         ips = udist.job_throughput(B, a.steps, elapsed, world)
         path_gbps = ips / world * path_bytes_per_image(H, H, K, F, cfg["tex"], cfg["tex"]) / 1e9
         result = {
@@ -183,19 +233,25 @@ def main():
                        "faces_per_mesh": F, "texture": [cfg["tex"], cfg["tex"]], "sigma": 1e-4,
                        "grads": a.grads, "launch": launch},
             "eager_images_per_s": round(udist.job_throughput(B, a.steps, eager_elapsed, world), 2),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                         "kernel_ms": round(raster_ms, 4), "dominant_call": dom_call,
-                         "kernels_ms": {k: round(v, 4) for k, v in sorted(kernel_ms.items())},
-                         "note": "algorithmic bytes = this launch's share of SURVEY 8(d) (fragments counted as if "
-                                 "materialised); the fused kernels recompute instead of storing fragments, so real "
-                                 "HBM traffic is far below it (traffic) and frac may pass 1: the kernel is bound by "
-                                 "VALU issue / latency, see DESIGN.md 6"},
+            "roofline": {"bound": "valu_issue", "kernel": dom, "achieved": rd.get("valu_Ginstr_per_s"),
+                         "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": rd.get("valu_issue_frac"),
+                         "traffic": rd.get("traffic"), "kernel_ms": rd["kernel_ms"], "dominant_call": calls[dom],
+                         "clock_GHz": CLOCK_GHZ, "simds": SIMDS, "clk_per_wave_valu_instr": CLK_PER_WAVE_VALU,
+                         "counters_from": os.path.relpath(COUNTERS, ROOT) if counters else None,
+                         "kernels": [roofs[k] for k in sorted(roofs)],
+                         "note": "achieved = SQ_INSTS_VALU per launch (rocprofv3 --pmc, committed under profiles/) / "
+                                 "the kernel's duration measured live with HIP events on its launch stream; peak = "
+                                 "1024 SIMDs x 2.4 GHz / 4 clk per wave64 VALU instruction.  The kernels are per-pixel "
+                                 "geometry tests, sorts and scatters: not streaming, no MFMA (DESIGN.md 6); SURVEY "
+                                 "8(d)'s byte model is kept as path_hbm / algorithmic_GBps (fragments counted as if "
+                                 "materialised; the fused kernels never store them, so that figure is not a bound)"},
             "path_hbm": {"bytes_per_image": path_bytes_per_image(H, H, K, F, cfg["tex"], cfg["tex"]),
                          "achieved_GBps_per_gpu": round(path_gbps, 2),
                          "frac_of_peak": round(path_gbps / HBM_PEAK_GBPS, 4)},
             "per_call_ms": {k: round(v[1], 4) for k, v in sorted(per_call.items())},
+            "ranks": {"backend": backend if world > 1 else None, "images_per_s": [round(v, 1) for v in per_rank],
+                      "allreduce_sum_of_ones": n_ranks_seen,
+                      "shared_gpus": bool(world > torch.cuda.device_count())},
         }
         if not a.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(cfg)

@@ -33,7 +33,8 @@ def _worker(rank, world, port, out):
 
     elapsed = udist.timed_steps(step, steps=3, warmup=1, world=w, cuda=False)
     out[rank] = dict(elapsed=elapsed, calls=len(calls), R00=float(sc["R"][0, 0, 0]),
-                     value=udist.job_throughput(2, 3, elapsed, w))
+                     value=udist.job_throughput(2, 3, elapsed, w), local=udist.last_local_elapsed(),
+                     rates=udist.gather_floats(10.0 + rank, w, cuda=False), ones=udist.sum_over_ranks(1.0, w, False))
     udist.finish(w)
 
 
@@ -47,6 +48,37 @@ def test_two_rank_sharding_and_timing():
     assert a["elapsed"] >= 3 * 0.03                           # the slow rank's time
     assert abs(a["value"] - 2 * 2 * 3 / a["elapsed"]) < 1e-9  # whole-job units / max time
     assert a["R00"] != b["R00"]                               # ranks render different shards
+    assert a["local"] < b["local"] <= b["elapsed"]            # each rank's own time, before the wait for the slowest
+    assert a["rates"] == b["rates"] == [10.0, 11.0] and a["ones"] == b["ones"] == 2.0  # per-rank line of bench.py
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without RANK in the environment (how the driver may call it) must start N ranks
+    itself (reference: trainer.py:284-290 spawns its ranks from the entry script) -- as a CHILD process, before
+    anything touches the GPU -- and pass the child's exit code on."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    assert bench.launch_own_ranks(2) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")
+    assert seen["env"].get("UNICORN_BENCH_BACKEND") == "gloo"  # no GPUs here: the ranks would share devices
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with __import__("pytest").raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
 
 
 def test_single_process_defaults():

@@ -38,6 +38,9 @@ def fence(world, cuda):
         torch.cuda.synchronize()
 
 
+_last_local = [0.0]
+
+
 def timed_steps(step, steps, warmup, world, cuda):
     """warmup untimed steps, then exactly `steps` timed ones between two fences; returns the MAX over ranks of the
     elapsed seconds (identical on every rank)."""
@@ -47,8 +50,34 @@ def timed_steps(step, steps, warmup, world, cuda):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if cuda:
+        torch.cuda.synchronize()
+    _last_local[0] = time.perf_counter() - t0  # this rank's own time, before waiting for the others
     fence(world, cuda)
     return max_over_ranks(time.perf_counter() - t0, world, cuda)
+
+
+def last_local_elapsed():
+    """this rank's own elapsed seconds in the last timed_steps (without the wait for the slowest rank)"""
+    return _last_local[0]
+
+
+def gather_floats(value, world, cuda):
+    """[value of rank 0, ..., value of rank world-1] on every rank"""
+    if world == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if cuda else "cpu")
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def sum_over_ranks(value, world, cuda):
+    if world == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
 
 
 def max_over_ranks(value, world, cuda):
