@@ -4,9 +4,10 @@
 
 Everything numeric runs in the hand-written HIP kernels behind include/unicorn_render.h; this file only composes them.
 """
+import math
 from copy import deepcopy
+from dataclasses import dataclass, field
 
-import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -289,94 +290,107 @@ class MeshRenderer(nn.Module):
 
 
 class VizMeshRenderer(MeshRenderer):
-    """Renderer for visualization, with anti-aliasing (2x supersampling + average pooling; renderer.py:119-124)"""
+    """The visualisation pipeline (renderer.py:119-124): the scene is rasterized at twice the requested size and
+    every 2x2 block of the result is averaged -- anti-aliasing by supersampling.  Never differentiated."""
 
-    @torch.no_grad()
-    def __call__(self, *input, **kwargs):
-        res = super().__call__(*input, **kwargs)
-        return F.avg_pool2d(res, kernel_size=2, stride=2)
+    def forward(self, meshes, **kwargs):
+        with torch.no_grad():
+            supersampled = super().forward(meshes, **kwargs)
+            return F.avg_pool2d(supersampled, 2)
+
+
+def _pair(size):
+    return (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+
+
+@dataclass(frozen=True)
+class RenderConfig:
+    """Resolved options of a `Renderer`.  Names and defaults are the reference's (renderer.py:26-57: `kwargs.get(name,
+    default)`), because configs and checkpoints carry them (`model_kwargs`, unicorn.py:46-47)."""
+    cameras: dict = field(default_factory=dict)     # {'name': 'fov' | 'perspective', + that camera's arguments}
+    lights: dict = field(default_factory=dict)      # {'name': 'ambient' | 'directional' | 'point', + arguments}
+    sigma: float = 1e-4
+    background_color: tuple = (1, 1, 1)
+    faces_per_pixel: int = 25
+    layered_shader: bool = LAYERED_SHADER
+    clip_inside: bool = True
+    shading_type: str = SHADING_TYPE
+    debug: bool = False
+    viz_size: tuple = (VIZ_IMG_SIZE, VIZ_IMG_SIZE)
+
+
+CAMERA_TYPES = {'fov': FoVPerspectiveCameras, 'perspective': PerspectiveCameras}
+LIGHT_TYPES = {'ambient': AmbientLights, 'directional': DirectionalLights, 'point': PointLights}
+# update_lights(direction, ka, kd, ks) -> attribute of the lights object (renderer.py:89-97)
+LIGHT_FIELDS = (('direction', 'direction'), ('ka', 'ambient_color'), ('kd', 'diffuse_color'), ('ks', 'specular_color'))
+
+
+def _from_spec(spec, types, default_name):
+    """{'name': type name, **arguments} -> instance (renderer.py:59-74)"""
+    args = {k: deepcopy(v) for k, v in spec.items() if k != 'name'}
+    return types[spec.get('name', default_name)](**args)
 
 
 class Renderer(nn.Module):
-    def __init__(self, img_size, **kwargs):
+    """Drop-in for the reference's `Renderer` (renderer.py:25-116).  Two pipelines share one camera and one set of
+    lights: `renderer` (soft rasterization for training: K faces per pixel, blur radius ln(1/1e-4 - 1) * sigma) and
+    `viz_renderer` (hard, one face per pixel, 2x supersampled).  An option left at None takes the reference's default
+    and stays out of `init_kwargs`, which therefore returns exactly what the caller passed."""
+
+    def __init__(self, img_size, *, cameras=None, lights=None, sigma=None, background_color=None, faces_per_pixel=None,
+                 layered_shader=None, clip_inside=None, shading_type=None, debug=None, viz_size=None):
         super().__init__()
-        img_size = (img_size, img_size) if isinstance(img_size, int) else img_size
-        self._init_kwargs = deepcopy(kwargs)
-        self.init_cameras(**kwargs.get('cameras', {}))
-        self.init_lights(**kwargs.get('lights', {}))
-        blend_kwargs = {'sigma': kwargs.get('sigma', 1e-4),
-                        'background_color': kwargs.get('background_color', (1, 1, 1))}
-        n_faces = kwargs.get('faces_per_pixel', 25)
-        blend_params = BlendParams(**blend_kwargs)
-        s_kwargs = {'cameras': self.cameras, 'lights': self.lights, 'blend_params': blend_params,
-                    'debug': kwargs.get('debug', False)}
-        if kwargs.get('layered_shader', LAYERED_SHADER):
-            shader_cls = LayeredShader
-            s_kwargs['clip_inside'] = kwargs.get('clip_inside', True)
-            s_kwargs['shading_type'] = kwargs.get('shading_type', SHADING_TYPE)
+        options = dict(cameras=cameras, lights=lights, sigma=sigma, background_color=background_color,
+                       faces_per_pixel=faces_per_pixel, layered_shader=layered_shader, clip_inside=clip_inside,
+                       shading_type=shading_type, debug=debug, viz_size=viz_size)
+        self._passed = deepcopy({k: v for k, v in options.items() if v is not None})
+        self.config = cfg = RenderConfig(**deepcopy(self._passed))
+        self.cameras = _from_spec(cfg.cameras, CAMERA_TYPES, 'fov')
+        self.lights = _from_spec(cfg.lights, LIGHT_TYPES, 'ambient')
+        # what reset_default_lights() goes back to after update_lights() (the eye-light GIFs, renderer.py:225-251)
+        self._light_defaults = {attr: getattr(self.lights, attr) for _, attr in LIGHT_FIELDS if hasattr(self.lights, attr)}
+        viz = _pair(cfg.viz_size)
+        self.renderer = self._pipeline(MeshRenderer, _pair(img_size), cfg.faces_per_pixel, cfg.sigma)
+        self.viz_renderer = self._pipeline(VizMeshRenderer, (2 * viz[0], 2 * viz[1]), 1, 0.0)
+
+    def _pipeline(self, kind, image_size, faces_per_pixel, sigma):
+        """rasterizer + shader for one (size, K, sigma): renderer.py:45-49 (training) and :51-57 (visualisation).  The
+        blur radius is where the blend's sigmoid falls to 1e-4: ln(1/1e-4 - 1) * sigma; 0 makes the raster hard."""
+        cfg = self.config
+        blend = BlendParams(sigma=sigma, background_color=cfg.background_color)
+        raster = RasterizationSettings(image_size=image_size, blur_radius=math.log(1.0 / 1e-4 - 1.0) * sigma,
+                                       faces_per_pixel=faces_per_pixel, perspective_correct=False)
+        common = dict(cameras=self.cameras, lights=self.lights, blend_params=blend, debug=cfg.debug)
+        if cfg.layered_shader:
+            shader = LayeredShader(clip_inside=cfg.clip_inside, shading_type=cfg.shading_type, **common)
         else:
-            shader_cls = SoftPhongShaderPlus
-
-        # approximative differentiable renderer for training (renderer.py:45-49)
-        raster_settings = RasterizationSettings(image_size=img_size,
-                                                blur_radius=np.log(1. / 1e-4 - 1.) * blend_params.sigma,
-                                                faces_per_pixel=n_faces, perspective_correct=False)
-        self.renderer = MeshRenderer(MeshRasterizer(cameras=self.cameras, raster_settings=raster_settings),
-                                     shader_cls(**s_kwargs))
-
-        # exact anti-aliased rendering for visualization (renderer.py:51-57)
-        viz_size = kwargs.get('viz_size', (VIZ_IMG_SIZE, VIZ_IMG_SIZE))
-        s_kwargs['blend_params'] = BlendParams(background_color=blend_kwargs['background_color'], sigma=0)
-        raster_settings = RasterizationSettings(image_size=(viz_size[0] * 2, viz_size[1] * 2), blur_radius=0.0,
-                                                faces_per_pixel=1, perspective_correct=False)
-        self.viz_renderer = VizMeshRenderer(MeshRasterizer(cameras=self.cameras, raster_settings=raster_settings),
-                                            shader_cls(**s_kwargs))
-
-    def init_cameras(self, **kwargs):
-        kwargs = deepcopy(kwargs)
-        name = kwargs.pop('name', 'fov')
-        cam_cls = {'fov': FoVPerspectiveCameras, 'perspective': PerspectiveCameras}[name]
-        self.cameras = cam_cls(**kwargs)
-
-    def init_lights(self, **kwargs):
-        kwargs = deepcopy(kwargs)
-        name = kwargs.pop('name', 'ambient')
-        light_cls = {'ambient': AmbientLights, 'directional': DirectionalLights, 'point': PointLights}[name]
-        self.lights = light_cls(**kwargs)
-        if name == 'directional':
-            self.lights._direction = self.lights.direction
-            self.lights._ambient_color = self.lights.ambient_color
-            self.lights._diffuse_color = self.lights.diffuse_color
-            self.lights._specular_color = self.lights.specular_color
+            shader = SoftPhongShaderPlus(**common)
+        return kind(MeshRasterizer(cameras=self.cameras, raster_settings=raster), shader)
 
     @property
     def init_kwargs(self):
-        return deepcopy(self._init_kwargs)
+        return deepcopy(self._passed)
 
     def forward(self, meshes, R, T, viz_purpose=False):
-        return self.viz_renderer(meshes, R=R, T=T) if viz_purpose else self.renderer(meshes, R=R, T=T)  # BCHW
+        """-> (N, 4, H, W) RGBA"""
+        pipeline = self.viz_renderer if viz_purpose else self.renderer
+        return pipeline(meshes, R=R, T=T)
 
     def to(self, device):
         super().to(device)
-        self.renderer = self.renderer.to(device)
-        self.viz_renderer = self.viz_renderer.to(device)
+        for pipeline in (self.renderer, self.viz_renderer):  # cameras and lights are not modules: moved by hand
+            pipeline.to(device)
         return self
 
     def update_lights(self, direction=None, ka=None, kd=None, ks=None):
-        if direction is not None:
-            self.lights.direction = direction
-        if ka is not None:
-            self.lights.ambient_color = ka
-        if kd is not None:
-            self.lights.diffuse_color = kd
-        if ks is not None:
-            self.lights.specular_color = ks
+        given = dict(direction=direction, ka=ka, kd=kd, ks=ks)
+        for arg, attr in LIGHT_FIELDS:
+            if given[arg] is not None:
+                setattr(self.lights, attr, given[arg])
 
     def reset_default_lights(self):
-        self.lights.direction = self.lights._direction
-        self.lights.ambient_color = self.lights._ambient_color
-        self.lights.diffuse_color = self.lights._diffuse_color
-        self.lights.specular_color = self.lights._specular_color
+        for attr, value in self._light_defaults.items():
+            setattr(self.lights, attr, value)
 
     @torch.no_grad()
     def compute_vertex_visibility(self, meshes, R, T):
