@@ -192,10 +192,10 @@ int ur_mesh_regularizers(const float* verts, int N, int V, const int32_t* edge_q
  * the blend stops at the first layer that hides everything behind it (alpha == 1 with zero d(alpha)/d(dist)), which
  * changes neither the image nor any gradient.  No (N,H,W,K) fragment tensors are materialised: the forward leaves
  * only `layers`, ur_layers_elems() int32 words, opaque to the caller: per 16x16-pixel bin and per wavefront of the
- * bin (4 x 64 pixels, every second column / row), per depth slot, six 64-pixel planes (packed face index; float bits
- * of the transmittance in front of the layer, its alpha and its colour) of the layers that matter, front to back,
- * followed by the per-pixel layer counts.  Only the first few depth slots are ever touched.  The backward also needs
- * ur_backward_scratch_bytes() of uninitialised device scratch.
+ * bin (4 x 64 pixels, every second column / row) the layers that matter, one 32-byte row each (packed face index,
+ * pixel, float bits of the transmittance in front of the layer, its alpha and its colour), the layers of a pixel front
+ * to back, pixel after pixel, followed by the per-pixel layer counts.  Only the rows of layers that exist are ever
+ * touched.  The backward also needs ur_backward_scratch_bytes() of uninitialised device scratch.
  *   workspace: ur_workspace_bytes(total_faces, N, H, W, K) bytes; the backward must be given the SAME buffer, untouched.
  *   grad_face_verts (NF,3,3) and grad_maps (N,Ht,Wt,3) must be zero-filled by the caller; either may be NULL
  *   (then that gradient is skipped).  The z column of grad_face_verts stays 0 (the layered blend never reads zbuf).

@@ -92,6 +92,21 @@ int static_scratch(void** out) {
   return UR_OK;
 }
 
+constexpr int kMaxDevices = 64;
+
+// compute units of the current device (cached per device)
+int device_cus() {
+  static std::atomic<int> cus[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v <= 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -101,7 +116,6 @@ int check_launch(const char* what) {
 // Kernels that want more than 64 KB of dynamic LDS must be told so once per (kernel, device).  `slot` is a small
 // table per call site: the largest size configured so far on each device (process-wide, relaxed atomics: a race only
 // repeats the idempotent call).
-constexpr int kMaxDevices = 64;
 struct LdsSlot { std::atomic<size_t> done[kMaxDevices]; };
 
 int ensure_dynamic_lds(const void* kernel, size_t bytes, LdsSlot& slot) {
@@ -435,11 +449,9 @@ struct RasterParams {
   int use_amb;
   int mode;
   float* image;     // (N,4,H,W)
-  int32_t* layers;  // [N][TH][TW][K][6][64]: per tile, per depth slot, six 64-lane planes (lane = pixel): face index,
-                    // transmittance in front of the layer, alpha, colour r g b (float bits) of the layers that
-                    // matter for the blend, front to back, ended by face = -1 (unless all K slots are used)
-  float* scratch;   // backward: [N][TH][TW][K][2][64] per-layer (dL/dalpha, weight) handed from the per-pixel sweep
-                    // to the evenly dealt gradient pass
+  int32_t* layers;  // per 64-pixel group K * 64 rows of kRowWords dwords (see kRowWords), then the per-pixel counts
+  float* scratch;   // backward: one float per layer row (dL/dalpha) handed from the per-pixel sweep to the evenly
+                    // dealt gradient pass
   const float* gimage;
   float* gmaps;
   float* gfv;
@@ -463,9 +475,15 @@ constexpr int kPreStride = 96;   // ints per wave in the pair-prefix array: 65 p
 // reaches K.  Up to 64 (128) entries a list is still sorted by one wave-wide network.
 __host__ __device__ inline int list_cap(int K) { return K <= 64 ? (2 * K < 64 ? 2 * K : 64) : (K <= 128 ? 128 : K); }
 
-// where the per-pixel layer counts start inside `layers` (after the [group][K][6][64] records)
+// `layers`: per 64-pixel wave group up to K * 64 layer ROWS of 8 dwords (32 bytes = one memory sector, written and read
+// as two dwordx4), in the group's pixel-major item order (the layers of pixel 0 front to back, then pixel 1, ...: row
+// index = exclusive prefix of the per-pixel layer counts + layer), followed by the per-pixel layer counts of all
+// groups.  Row = { packed face index, pixel (lane) of the group, transmittance in front of the layer, alpha,
+//                  r, g, b, 0 }   (float bits)
+constexpr int kRowWords = 8;
+// where the per-pixel layer counts start inside `layers` (after the [group][K * 64] rows)
 __host__ __device__ inline int64_t layer_counts_offset(int N, int nbx, int nby, int K) {
-  return (int64_t)N * nbx * nby * 4 * K * 6 * 64;
+  return (int64_t)N * nbx * nby * 4 * K * 64 * kRowWords;
 }
 
 __device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float xc_hi, float yc_lo, float yc_hi) {
@@ -1153,9 +1171,9 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     s_pre[lane] = pre;
     // the staging buffers are dead once the fine step is over (every wave is past its last barrier): this wave's
     // slice of them carries the batch's (alpha, r, g, b) from the lanes that computed them to the pixels' owners
-    float4* s_res = s_rec + wave * 128;
-    int32_t* lay_tile = P.layers + tile_id * (int64_t)K * 6 * 64;  // [K][6 words][64 lanes]
-    int32_t* lay = lay_tile + lane;
+    float4* s_res = s_rec + wave * 160;                      // 128 float4: (alpha, r, g, b) of a round's items
+    float* s_occ = reinterpret_cast<float*>(s_res + 128);    // 128 floats: transmittance in front of each of them
+    int4* lay_rows = reinterpret_cast<int4*>(P.layers + tile_id * (int64_t)K * 64 * kRowWords);  // [item][2 x int4]
     float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
     // One round takes 64 U items, U per lane.  The item phase is a chain of dependent memory round trips (key ->
     // record + UVs -> texels) with little arithmetic in between, so two items per lane are walked through it side by
@@ -1211,29 +1229,28 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (P.use_amb) { vr[u] *= P.amb[0]; vg[u] *= P.amb[1]; vb[u] *= P.amb[2]; }
-        // the layer record for the backward, written by whoever computed it (plane 1, the transmittance in front of
-        // the layer, comes from the pixel's owner below)
-        if (act[u]) {
-          int32_t* le = lay_tile + (int64_t)ik[u] * 6 * 64 + il[u];
-          le[0] = ifid[u];
-          le[128] = __float_as_int(va[u]);
-          le[192] = __float_as_int(vr[u]);
-          le[256] = __float_as_int(vg[u]);
-          le[320] = __float_as_int(vb[u]);
-        }
         s_res[64 * u + lane] = make_float4(va[u], vr[u], vg[u], vb[u]);
       }
-      // owners composite their items of this round, in depth order
+      // owners composite their items of this round, in depth order, and leave the transmittance in front of each
       const int s0 = max(pre, base), e0 = min(pre + m, base + 64 * U);
       const int nloop = __builtin_amdgcn_readfirstlane(wave_max(max(e0 - s0, 0)));
       for (int t = 0; t < nloop; ++t) {
         if (s0 + t < e0) {
           const float4 c = s_res[s0 + t - base];
-          lay[(int64_t)(s0 + t - pre) * 6 * 64 + 64] = __float_as_int(occ);
+          s_occ[s0 + t - base] = occ;
           r += occ * c.x * c.y; g += occ * c.x * c.z; b += occ * c.x * c.w;
           occ = occ * (1.0f - c.x);
         }
       }
+      // the layer rows for the backward, written by the lanes that computed them: 64 consecutive 32-byte rows per
+      // store instruction
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (act[u]) {
+          int4* row = lay_rows + (int64_t)(base + 64 * u + lane) * 2;
+          row[0] = make_int4(ifid[u], il[u], __float_as_int(s_occ[64 * u + lane]), __float_as_int(va[u]));
+          row[1] = make_int4(__float_as_int(vr[u]), __float_as_int(vg[u]), __float_as_int(vb[u]), 0);
+        }
     };
     int base = 0;
     for (; base + 64 < total; base += 128) round(std::integral_constant<int, 2>{}, base);
@@ -1554,7 +1571,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   __shared__ double s_fval[kFaceSlots * 6];
   __shared__ int s_ttag[kTexSlots];
   __shared__ double s_tval[kTexSlots * 3];
-  __shared__ int s_pre_all[4 * 136];  // per wave: 64 compacted pixels, then their 65 + pad first-item indices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = P.H, W = P.W, K = P.K;
   // same workgroup schedule and pixel ownership as the forward: heaviest bins first; wave w holds every second
@@ -1568,102 +1584,113 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   const int x = tx0 + 2 * (lane & 7), y = ty0 + 2 * (lane >> 3);
   const bool live = (x < W) && (y < H);
   const int64_t tile_id = (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
-  const int32_t* lay_tile = P.layers + (tile_live ? tile_id : 0) * (int64_t)K * 6 * 64;  // [K][6][64]
-  const int32_t* lay = lay_tile + lane;
-  float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 2 * 64;         // [K][2][64]
+  // the group's layer rows (layout: kRowWords) and one float of scratch per row
+  const int4* lay_rows = reinterpret_cast<const int4*>(P.layers + (tile_live ? tile_id : 0) * (int64_t)K * 64 * kRowWords);
+  float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 64;  // [item]: dL/dalpha of the layer
   float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
 
-  // this pixel's layer count (left by the forward)
+  // this pixel's layer count (left by the forward); the group's rows are in pixel-major item order: this pixel's
+  // layers are rows [pre, pre + m)
   const int m = (tile_live && live) ? P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] : 0;
-  const int maxm = __builtin_amdgcn_readfirstlane(wave_max(m));
-  if (!__syncthreads_or(maxm > 0)) return;  // nothing rendered in this bin
+  const int incl = wave_scan_add(m);
+  const int pre = incl - m;
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  if (!__syncthreads_or(total > 0)) return;  // nothing rendered in this bin
+  const int lo = 0, hi = total;
   for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
   for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0;
   for (int i = tid; i < kTexSlots; i += 256) s_ttag[i] = -1;
   for (int i = tid; i < kTexSlots * 3; i += 256) s_tval[i] = 0.0;
   __syncthreads();
 
-  if (maxm > 0) {
+  if (hi > lo) {
     const int64_t hw = (int64_t)H * W;
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
     if (live) {
       const float* gi = P.gimage + (int64_t)n * 4 * hw + (int64_t)y * W + x;
       g0 = gi[0]; g1 = gi[hw]; g2 = gi[2 * hw]; g3 = gi[3 * hw];
     }
-    // ---- (a) per pixel, back to front, from what the forward saved per layer (transmittance in front, alpha,
-    //      colour): dL/dalpha_k and the colour weight occ_k a_k.  Two layers' loads are issued together.
+    // ---- (a) dL/dalpha of every layer row, one float per row.  With f_j(x) = a_j (c_j . g) + (1 - a_j) x, the colour
+    //      composited behind layer i of a pixel is f_{i+1}(f_{i+2}(... f_last(bg . g))) and the transmittance behind it
+    //      the product of the (1 - a_j): a suffix composition of affine maps over the pixel's rows.  Rows are walked
+    //      64 at a time from the end of the group's list (lane = row, coalesced loads, the next 64 in flight), the
+    //      suffixes come from a segmented wave scan (segments = pixels) and the open segment's map is carried from
+    //      batch to batch -- work in proportion to the rows, not to the deepest pixel of the group.
     {
-      float behind = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
-      float trans = 1.0f;
-      auto sweep = [&](int k, float occ, float a, float cr, float cgc, float cb) {
-        const float cg = g0 * cr + g1 * cgc + g2 * cb;
-        float* sc = scr_tile + (int64_t)k * 2 * 64 + lane;
-        sc[0] = occ * (cg - behind) + g3 * occ * trans;
-        sc[64] = occ * a;
-        behind = a * cg + (1.0f - a) * behind;
-        trans = trans * (1.0f - a);
+      const float bgdot_own = g0 * P.bg[0] + g1 * P.bg[1] + g2 * P.bg[2];
+      float carry_m = 1.0f, carry_c = 0.0f;  // composition of the rows after this batch that belong to the pixel of its last row
+      const int first_base = ((total - 1) >> 6) << 6;
+      auto load_rows = [&](int base, int4& ra, int4& rb) {
+        const int i = base + 63 - lane;
+        if (base >= 0 && i < total) { ra = lay_rows[(int64_t)i * 2]; rb = lay_rows[(int64_t)i * 2 + 1]; }
       };
-      for (int kb = maxm - 1; kb >= 0; kb -= 2) {
-        const int k1 = kb, k0 = kb - 1;
-        const bool h1 = k1 < m, h0 = k0 >= 0 && k0 < m;
-        const int32_t* l1 = lay + (int64_t)k1 * 6 * 64;
-        const int32_t* l0 = lay + (int64_t)(k0 < 0 ? 0 : k0) * 6 * 64;
-        float o1 = 0, a1 = 0, r1 = 0, gg1 = 0, b1 = 0, o0 = 0, a0 = 0, r0 = 0, gg0 = 0, b0 = 0;
-        if (h1) { o1 = __int_as_float(l1[64]); a1 = __int_as_float(l1[128]); r1 = __int_as_float(l1[192]);
-                  gg1 = __int_as_float(l1[256]); b1 = __int_as_float(l1[320]); }
-        if (h0) { o0 = __int_as_float(l0[64]); a0 = __int_as_float(l0[128]); r0 = __int_as_float(l0[192]);
-                  gg0 = __int_as_float(l0[256]); b0 = __int_as_float(l0[320]); }
-        if (h1) sweep(k1, o1, a1, r1, gg1, b1);
-        if (h0) sweep(k0, o0, a0, r0, gg0, b0);
+      int4 ra_n = make_int4(0, 0, 0, 0), rb_n = ra_n;
+      load_rows(first_base, ra_n, rb_n);
+      for (int base = first_base; base >= 0; base -= 64) {
+        const int i = base + 63 - lane;  // lane 0 takes the batch's last row: lanes run back to front
+        const bool act = i < total;
+        const int4 ra = ra_n, rb = rb_n;
+        load_rows(base - 64, ra_n, rb_n);
+        const int p = act ? ra.y : lane;
+        const float q0 = __shfl(g0, p, 64), q1 = __shfl(g1, p, 64), q2 = __shfl(g2, p, 64), q3 = __shfl(g3, p, 64);
+        const float bgdot = __shfl(bgdot_own, p, 64);
+        const int pend = __shfl(incl, p, 64);          // one past the pixel's last row
+        const float occ = __int_as_float(ra.z), al = __int_as_float(ra.w);
+        const float cg = q0 * __int_as_float(rb.x) + q1 * __int_as_float(rb.y) + q2 * __int_as_float(rb.z);
+        // inclusive segmented scan of the maps (M, C): x -> M x + C, lane q composing on the left of lanes < q
+        int F = (act && i + 1 == pend) ? 1 : 0;        // the pixel's farthest layer starts a segment
+        float M = act ? 1.0f - al : 1.0f, C = act ? al * cg : 0.0f;
+#define UR_SEG_STEP(CTRL, ROWMASK)                                                                                   \
+        {                                                                                                            \
+          const int fs = __builtin_amdgcn_update_dpp(0, F, CTRL, ROWMASK, 0xf, false);                               \
+          const float ms = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(M), CTRL, ROWMASK, 0xf, false)); \
+          const float cs = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(C), CTRL, ROWMASK, 0xf, false));          \
+          if (!F) { C = M * cs + C; M = M * ms; }                                                                    \
+          F |= fs;                                                                                                   \
+        }
+        UR_SEG_STEP(0x111, 0xf) UR_SEG_STEP(0x112, 0xf) UR_SEG_STEP(0x114, 0xf) UR_SEG_STEP(0x118, 0xf)
+        UR_SEG_STEP(0x142, 0xa) UR_SEG_STEP(0x143, 0xc)
+#undef UR_SEG_STEP
+        if (!F) { C = M * carry_c + C; M = M * carry_m; }  // still inside the segment left open by the previous batch
+        // exclusive value: the lane before (the previous batch's carry for lane 0), identity at a segment start
+        float Me = __shfl_up(M, 1, 64), Ce = __shfl_up(C, 1, 64);
+        if (lane == 0) { Me = carry_m; Ce = carry_c; }
+        if (act && i + 1 == pend) { Me = 1.0f; Ce = 0.0f; }
+        carry_m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(M), 63));
+        carry_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C), 63));
+        if (act) {
+          const float behind = Me * bgdot + Ce;
+          scr_tile[i] = occ * (cg - behind) + q3 * occ * Me;
+        }
       }
     }
-    // ---- (b) the tile's (pixel, layer) items dealt out evenly over the lanes: geometry is re-evaluated once per
-    //      item, gradients go to the LDS tables
-    const int incl = wave_scan_add(m);
-    const int pre = incl - m;
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    // Lane L takes the items [L nb, (L+1) nb) of the tile's pixel-major item list, nb = batches: in any one batch the
-    // 64 lanes then sit in 64 different neighbourhoods of the tile, so few of them meet on the same face / texel --
-    // an LDS atomic costs ~12 clocks per extra lane on its address.  The pixels that have layers are compacted into
-    // (pixel, count) / first-item arrays; a lane finds its first item by binary search and then just walks on.
-    int* s_own = s_pre_all + wave * 136;   // 64 entries: pixel | count << 8
-    int* s_opre = s_own + 64;              // 65 entries: first item of the r-th pixel with layers, then sentinels
-    const unsigned long long om = __ballot(m > 0);
-    const int nown = __popcll(om);
-    if (m > 0) {
-      const int rank = __popcll(om & ((1ull << lane) - 1ull));
-      s_own[rank] = lane | (m << 8);
-      s_opre[rank] = pre;
-    }
-    if (lane >= nown) s_opre[lane] = 0x7fffffff;
-    if (lane == 0) s_opre[64] = 0x7fffffff;
-    const int nbatch = (total + 63) >> 6;
-    const int item0 = lane * nbatch;
-    int rr = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1)
-      if (s_opre[rr + step] <= item0) rr += step;
-    int k = item0 - s_opre[rr];
-    int ow = s_own[rr];
+    // ---- (b) the group's (pixel, layer) items dealt out evenly over the lanes: geometry is re-evaluated once per
+    //      item, gradients go to the LDS tables.  Lane L takes the items [L nb, (L+1) nb) of the item list, nb =
+    //      batches: in any one batch the 64 lanes then sit in 64 different neighbourhoods of the group, so fewer of
+    //      them meet on the same face / texel -- an LDS atomic costs ~12 clocks per extra lane on its address.  A row
+    //      names its pixel, so an item is one 16-byte load away; the next item's row is fetched a batch ahead.
+    const int nbatch = (hi - lo + 63) >> 6;
+    const int item0 = lo + lane * nbatch;
+    const float own_px = pix_to_ndc(W - 1 - x, W, H), own_py = pix_to_ndc(H - 1 - y, H, W);
     const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
     const bool clip = P.clip != 0;
-    for (int bi = 0; bi < nbatch; ++bi, ++k) {
-      if (k >= (ow >> 8)) {  // on to the next pixel that has layers
-        rr = min(rr + 1, 63);
-        ow = s_own[rr];
-        k = 0;
-      }
+    int4 row_next = make_int4(0, 0, 0, 0);
+    float ga_next = 0.0f;
+    if (item0 < hi) { row_next = lay_rows[(int64_t)item0 * 2]; ga_next = scr_tile[item0]; }
+    for (int bi = 0; bi < nbatch; ++bi) {
       const int item = item0 + bi;
-      int l = ow & 255;
-      if (item >= total) l = lane;
-      // cotangent of the owner pixel (all lanes take part in the shuffles)
+      const bool act = item < hi;
+      const int4 row = row_next;
+      const float ga = ga_next;
+      if (bi + 1 < nbatch && item + 1 < hi) { row_next = lay_rows[(int64_t)(item + 1) * 2]; ga_next = scr_tile[item + 1]; }
+      const int l = act ? row.y : lane;
+      // cotangent and pixel centre of the owner pixel (all lanes take part in the shuffles)
       const float q0 = __shfl(g0, l, 64), q1 = __shfl(g1, l, 64), q2 = __shfl(g2, l, 64);
-      if (item >= total) continue;
-      const int32_t* le = lay_tile + (int64_t)k * 6 * 64 + l;
-      const int fid = le[0];
-      const float a = __int_as_float(le[128]);
-      const float ga = scr_tile[(int64_t)k * 2 * 64 + l], wgt = scr_tile[(int64_t)k * 2 * 64 + 64 + l];
-      const float px = pix_to_ndc(W - 1 - (tx0 + 2 * (l & 7)), W, H), py = pix_to_ndc(H - 1 - (ty0 + 2 * (l >> 3)), H, W);
+      const float px = __shfl(own_px, l, 64), py = __shfl(own_py, l, 64);
+      if (!act) continue;
+      const int fid = row.x;
+      const float a = __int_as_float(row.w);
+      const float wgt = __int_as_float(row.z) * a;  // transmittance in front of the layer x its alpha
       const Face fc = load_face(P.rec, fid);
       const float* fup = face_uv_row(P, n, fid);
       const float fu[6] = {fup[0], fup[1], fup[2], fup[3], fup[4], fup[5]};  // in flight with the record
@@ -2620,11 +2647,11 @@ int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* 
 }
 
 size_t ur_backward_scratch_bytes(int N, int H, int W, int K) {
-  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * (size_t)K * 64 * 2 * 4;
+  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * (size_t)K * 64 * 4;
 }
 
 size_t ur_layers_elems(int N, int H, int W, int K) {
-  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * ((size_t)K * 64 * 6 + 64);
+  return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * ((size_t)K * 64 * kRowWords + 64);
 }
 
 static int fill_render_params(RasterParams& P, const int64_t* first, const int64_t* nfaces, int N, int H, int W,
@@ -2663,13 +2690,14 @@ int ur_render_layered_forward(const float* face_verts, const int64_t* mesh_first
   return launch_raster<2>(P, st);
 }
 
-int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_first_face,
-                               const int64_t* mesh_num_faces, int N, int64_t total_faces, int H, int W,
-                               float blur_radius, int K, int clip_barycentric_coords, const float* maps,
-                               const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
-                               const float* background, const float* ambient, int mode, const int32_t* layers,
-                               const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
-                               float* grad_face_verts, float* grad_maps, void* stream) {
+// eqF > 0: every mesh has eqF faces and mesh n starts at face n * eqF (the one-call path: no first[n] load in the kernel)
+static int layered_backward(const float* grad_image, const int64_t* mesh_first_face,
+                            const int64_t* mesh_num_faces, int N, int64_t total_faces, int H, int W,
+                            float blur_radius, int K, int clip_barycentric_coords, const float* maps,
+                            const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                            const float* background, const float* ambient, int mode, const int32_t* layers,
+                            const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                            float* grad_face_verts, float* grad_maps, void* stream, int eqF) {
   if (!grad_image || !layers || !workspace || !scratch) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (scratch_bytes < ur_backward_scratch_bytes(N, H, W, K)) return fail(UR_ERR_WORKSPACE, "scratch too small");
   if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
@@ -2685,6 +2713,7 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
   P.layers = const_cast<int32_t*>(layers);
   P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
   P.scratch = reinterpret_cast<float*>(scratch);
+  P.eqF = eqF;
   P.nbx = (W + 15) / 16;
   P.nby = (H + 15) / 16;
   const int64_t blocks = (int64_t)N * P.nbx * P.nby;
@@ -2694,6 +2723,19 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
     hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
   }
   return check_launch("k_render_bwd");
+}
+
+int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_first_face,
+                               const int64_t* mesh_num_faces, int N, int64_t total_faces, int H, int W,
+                               float blur_radius, int K, int clip_barycentric_coords, const float* maps,
+                               const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
+                               const float* background, const float* ambient, int mode, const int32_t* layers,
+                               const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                               float* grad_face_verts, float* grad_maps, void* stream) {
+  return layered_backward(grad_image, mesh_first_face, mesh_num_faces, N, total_faces, H, W, blur_radius, K,
+                          clip_barycentric_coords, maps, face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient,
+                          mode, layers, workspace, workspace_bytes, scratch, scratch_bytes, grad_face_verts, grad_maps,
+                          stream, 0);
 }
 
 
@@ -2774,10 +2816,10 @@ int ur_render_meshes_backward(const float* grad_image, const float* verts, const
     if (grad_maps && hipMemsetAsync(grad_maps, 0, (size_t)N * Ht * Wt * 12, st) != hipSuccess)
       return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
   }
-  int rc = ur_render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, N, NF, H, W, blur_radius, K,
-                                      clip_barycentric_coords, maps, face_uvs, face_uvs_shared, Ht, Wt, sigma, background,
-                                      ambient, mode, layers, workspace, workspace_bytes, scratch, scratch_bytes,
-                                      geometry ? grad_face_verts : nullptr, grad_maps, stream);
+  int rc = layered_backward(grad_image, mesh_first_face, mesh_num_faces, N, NF, H, W, blur_radius, K,
+                            clip_barycentric_coords, maps, face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient,
+                            mode, layers, workspace, workspace_bytes, scratch, scratch_bytes,
+                            geometry ? grad_face_verts : nullptr, grad_maps, stream, F);
   if (rc || !geometry) return rc;
   return ur_project_faces_backward(verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts, grad_verts,
                                    grad_R, grad_T, stream);
