@@ -1323,6 +1323,11 @@ constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4
 // pixel's blur disc the lists run deep and LDS residency pays more than occupancy (measured: 5120 faces at 128^2
 // +9 % with three workgroups per CU, 20480 faces at 256^2 / K=100 +12 % with two), so the budget follows the mesh's
 // face density on the image: faces per pixel >= 0.2 -> three workgroups per CU, and two when K > 64 as well.
+// the fused backward's table shapes follow the same density threshold (see k_render_bwd)
+bool render_bwd_dense(int64_t total_faces, int N, int H, int W) {
+  return (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W) >= 0.2;
+}
+
 int raster_cap(int64_t total_faces, int N, int H, int W, int K) {
   const int KL = list_cap(K);
   const double density = (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W);
@@ -1529,8 +1534,14 @@ __global__ void __launch_bounds__(256) k_raster_bwd(const float* __restrict__ fv
 // extra lane on the same address) but serialises ds_add_f32 lane by lane (~4 clk per active lane, ~250 clk per wave
 // instruction; tools/micro/lds_atomic*.hip) -- f64 sums are 5x faster here and more accurate.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kFaceSlots = 512;  // x 6 sums
-constexpr int kTexSlots = 256;   // x 3 sums ; slot = 16x16 torus over (texel row, texel column)
+// Table shapes (template arguments of k_render_bwd; 4 workgroups per CU need <= 40 KB together):
+//   FS face slots (x 6 sums), home slot = face index mod FS;
+//   16 x TC texel slots (x 3 sums), home slot = torus over (texel row, texel column): the texels of one contiguous
+//   footprint never collide.
+// Coarse meshes put few faces but long strips of texels into a bin (256 / 512: 27 KB), fine meshes the other way
+// round (512 / 256: 33 KB); the host picks by the mesh's face density on the image (render_bwd_dense).
+constexpr int kProbes = 3;       // slots tried per key (open addressing) before a contribution goes to global memory
+constexpr int kProbeStep = 73;   // odd, and far from the torus neighbours that a footprint fills next
 
 __device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, float px, float py, bool clip, float g0,
                                               float g1, float g2, float o[6]) {
@@ -1560,13 +1571,22 @@ __device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, flo
   o[0] += a0x; o[1] += a0y; o[2] += a1x; o[3] += a1y; o[4] += a2x; o[5] += a2y;
 }
 
-// claim-or-match a slot of an LDS table; true when `key` owns slot h
-__device__ __forceinline__ bool lds_claim(int* tags, int h, int key) {
-  const int old = atomicCAS(&tags[h], -1, key);
-  return old == -1 || old == key;
+// claim-or-match a slot for `key` in an open-addressed LDS tag table of `slots` (a power of two) entries, starting at
+// its home slot h; returns the slot, or -1 when kProbes slots were all taken by other keys.  A global float atomic
+// costs far more than a few LDS round trips (4 % of the texel adds going to global memory were 7 us of a 53 us kernel).
+__device__ __forceinline__ int lds_claim(int* tags, int h, int key, int slots) {
+#pragma unroll
+  for (int i = 0; i < kProbes; ++i) {
+    const int s = (h + i * kProbeStep) & (slots - 1);
+    const int old = atomicCAS(&tags[s], -1, key);
+    if (old == -1 || old == key) return s;
+  }
+  return -1;
 }
 
+template <int kFaceSlots, int kTexCols>
 __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
+  constexpr int kTexSlots = 16 * kTexCols;
   __shared__ int s_ftag[kFaceSlots];
   __shared__ double s_fval[kFaceSlots * 6];
   __shared__ int s_ttag[kTexSlots];
@@ -1729,19 +1749,18 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
           // texel (row, column) straight from the footprint: flipped rows Ht-1-y0 / Ht-2-y0, columns x0 / x0+1
           const int r0 = P.Ht - 1 - bl.y0, c0 = bl.x0;
           int hs[4], tx[4];
-          bool own[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int trow = r0 - (q >> 1), tcol = c0 + (q & 1);
             tx[q] = trow * P.Wt + tcol;
-            hs[q] = ((trow & 15) << 4) | (tcol & 15);
+            hs[q] = ((trow & 15) * kTexCols) | (tcol & (kTexCols - 1));
           }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) own[q] = (offs[q] >= 0) && lds_claim(s_ttag, hs[q], tx[q]);
+          for (int q = 0; q < 4; ++q) hs[q] = (offs[q] >= 0) ? lds_claim(s_ttag, hs[q], tx[q], kTexSlots) : -1;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             if (offs[q] < 0) continue;
-            if (own[q]) {
+            if (hs[q] >= 0) {
 #pragma unroll
               for (int ch = 0; ch < 3; ++ch) atomicAdd(&s_tval[hs[q] * 3 + ch], (double)(gc[ch] * wts[q]));
             } else {
@@ -1762,8 +1781,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
           seg_bwd(px, py, fc.v1x, fc.v1y, fc.v2x, fc.v2y, gs, o[2], o[3], o[4], o[5]);
       }
       if (P.gfv && (wgt != 0.0f || gd != 0.0f)) {
-        const int h = fid & (kFaceSlots - 1);
-        if (lds_claim(s_ftag, h, fid)) {
+        const int h = lds_claim(s_ftag, fid & (kFaceSlots - 1), fid, kFaceSlots);
+        if (h >= 0) {
 #pragma unroll
           for (int i = 0; i < 6; ++i)
             if (o[i] != 0.0f) atomicAdd(&s_fval[h * 6 + i], (double)o[i]);
@@ -2720,7 +2739,10 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
   {
     ProfScope prof(UR_PROFILE_RENDER_BWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    if (render_bwd_dense(total_faces, N, H, W))
+      hipLaunchKernelGGL((k_render_bwd<512, 16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    else
+      hipLaunchKernelGGL((k_render_bwd<256, 32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
   }
   return check_launch("k_render_bwd");
 }
