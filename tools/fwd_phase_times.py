@@ -29,8 +29,11 @@ L.ur_dev_set_timing.restype = None
 
 
 def run():
-    return native.render_layered_forward(fv, first, num, (H, H), blur, K, True, sc["maps"], fuv, True, sigma,
-                                         (1, 1, 1), None, 1)
+    if os.environ.get("UR_DEV_TWO_STEP"):  # projected faces in: per-face prep kernel, box scan in the rasterizer
+        return native.render_layered_forward(fv, first, num, (H, H), blur, K, True, sc["maps"], fuv, True, sigma,
+                                             (1, 1, 1), None, 1)
+    return native.render_meshes_forward(sc["verts"], sc["faces"], sc["R"], sc["T"], s, s, first, num, (H, H), blur, K,
+                                        True, sc["maps"], fuv, True, sigma, (1, 1, 1), None, 1)
 
 
 for _ in range(3):

@@ -168,6 +168,17 @@ __device__ __forceinline__ float wave_fmax(float v) {
 }
 
 constexpr int kPrepBins = 4096;  // bins per image the face-prep kernel counts in LDS (16 KB); beyond: global atomics
+// Face masks (k_project_prep_mesh -> k_raster<2, ., true>): per (mesh, bin, part) 256 bits, bit j = face part * 256 + j
+// of the mesh passes the bin's box test.  Up to kMaskBins bins per image, at most kMaskAxis of them along either axis.
+constexpr int kMaskBins = 1024;
+constexpr int kMaskAxis = 256;
+constexpr int kEmptyBin = 0x40000000;  // flag on a schedule entry: no face box reaches the bin
+constexpr int kBinIndex = 0x3fffffff;
+
+__device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float xc_hi, float yc_lo, float yc_hi) {
+  // bb = xlo xhi ylo yhi ; reject iff the whole centre interval is on one side of the box
+  return !(xc_hi < bb.x || xc_lo > bb.y || yc_hi < bb.z || yc_lo > bb.w);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // face records
@@ -271,7 +282,9 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
 
 // Workgroup schedule: bins sorted by descending load estimate (counting sort over 256 load classes, one workgroup).
 // The long-running bins -- silhouettes, where many faces pile up -- then start first and the cheap ones fill the gaps
-// at the end, instead of a late heavy bin stretching the kernel.  Any permutation gives the same results.
+// at the end, instead of a late heavy bin stretching the kernel.  Any permutation gives the same results.  A bin whose
+// load is zero is flagged (kEmptyBin): the load counts every face whose box, taken a pixel wider, reaches the bin, so no
+// face box passes such a bin's test and the kernels skip their face scan / row sweep for it.
 __global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binload, int n_bins, int* __restrict__ order,
                                                     int parts, int bins_per_mesh) {
   __shared__ int s_hist[256];
@@ -329,7 +342,7 @@ __global__ void __launch_bounds__(1024) k_bin_order(const int* __restrict__ binl
     }
   }
   __syncthreads();
-  each([&](int x, int i) { order[atomicAdd(&s_hist[cls(x, i)], 1)] = i; });
+  each([&](int x, int i) { order[atomicAdd(&s_hist[cls(x, i)], 1)] = x <= 0 ? (i | kEmptyBin) : i; });
 }
 
 // camera: view = X R + T, x_ndc = sx x / z, y_ndc = sy y / z, depth = view z (operation order fixed: part of the parity contract)
@@ -343,7 +356,7 @@ __device__ __forceinline__ void project_vertex(const float* __restrict__ p, cons
   out[2] = vz;
 }
 
-constexpr int kMeshPrepMaxFaces = 8192;  // up to here the per-mesh prep kernel (<= 32 workgroups per mesh)
+constexpr int kMeshPrepMaxFaces = 32768;  // up to here the per-mesh prep kernel (<= 128 workgroups per mesh)
 
 // workgroups per mesh of k_project_prep_mesh = partial load counts per (mesh, bin); 1 when that kernel is not used
 __host__ __device__ inline int prep_parts(int64_t total_faces, int N) {
@@ -362,11 +375,27 @@ __global__ void __launch_bounds__(256) k_project_prep_mesh(
     const float* __restrict__ verts, const int64_t* __restrict__ faces, int64_t fstride, const float* __restrict__ R,
     const float* __restrict__ T, float sx, float sy, int N, int V, int F, float r, int cull, int H, int W,
     float* __restrict__ face_verts, float4* __restrict__ bbox, float4* __restrict__ rec, float* __restrict__ fz,
-    int* __restrict__ binload, float* __restrict__ zero_a, int zero_a_n, float* __restrict__ zero_b, int zero_b_n) {
+    int* __restrict__ binload, unsigned* __restrict__ masks, float* __restrict__ zero_a, int zero_a_n,
+    float* __restrict__ zero_b, int zero_b_n) {
   __shared__ int s_load[kPrepBins];
+  __shared__ unsigned s_mask[kMaskBins * 8];
+  __shared__ float s_ext[4 * kMaskAxis];  // per bin column: x centres lo / hi ; per bin row: y centres lo / hi
   const int part = blockIdx.x, parts = gridDim.x, n = blockIdx.y, tid = threadIdx.x;
   const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nbins = nbx * nby;
   for (int j = tid; j < nbins; j += 256) s_load[j] = 0;
+  if (masks) {
+    // With masks the per-bin test is k_raster's own (the bin's pixel-centre extents against the box), so that the
+    // mask IS the bin list and the load its length.
+    for (int j = tid; j < nbins * 8; j += 256) s_mask[j] = 0u;
+    for (int j = tid; j < nbx; j += 256) {
+      s_ext[j] = pix_to_ndc(W - 1 - (min(W, j * 16 + 16) - 1), W, H);
+      s_ext[kMaskAxis + j] = pix_to_ndc(W - 1 - j * 16, W, H);
+    }
+    for (int j = tid; j < nby; j += 256) {
+      s_ext[2 * kMaskAxis + j] = pix_to_ndc(H - 1 - (min(H, j * 16 + 16) - 1), H, W);
+      s_ext[3 * kMaskAxis + j] = pix_to_ndc(H - 1 - j * 16, H, W);
+    }
+  }
   if (zero_a) {
     float* z = zero_a + (int64_t)n * zero_a_n;
     for (int j = part * 256 + tid; j < zero_a_n; j += parts * 256) z[j] = 0.0f;
@@ -401,12 +430,22 @@ __global__ void __launch_bounds__(256) k_project_prep_mesh(
       int c0, c1, r0, r1;
       box_pixels(bb, H, W, c0, c1, r0, r1);
       for (int by = r0 >> 4; by <= (r1 >> 4); ++by)
-        for (int bx = c0 >> 4; bx <= (c1 >> 4); ++bx) atomicAdd(&s_load[by * nbx + bx], 1);
+        for (int bx = c0 >> 4; bx <= (c1 >> 4); ++bx) {
+          if (masks) {
+            if (!bbox_overlap(bb, s_ext[bx], s_ext[kMaskAxis + bx], s_ext[2 * kMaskAxis + by], s_ext[3 * kMaskAxis + by]))
+              continue;
+            atomicOr(&s_mask[(by * nbx + bx) * 8 + (tid >> 5)], 1u << (tid & 31));
+          }
+          atomicAdd(&s_load[by * nbx + bx], 1);
+        }
     }
   }
   __syncthreads();
   int* out = binload + ((int64_t)n * parts + part) * nbins;
   for (int j = tid; j < nbins; j += 256) out[j] = s_load[j];
+  if (masks)  // [mesh][bin][part][8 words]: the parts of a bin lie side by side
+    for (int j = tid; j < nbins * 8; j += 256)
+      masks[(((int64_t)n * nbins + (j >> 3)) * parts + part) * 8 + (j & 7)] = s_mask[j];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -427,7 +466,9 @@ struct RasterParams {
   int cap;       // K-list slots per lane held in LDS
   int KL;        // K-list capacity (list_cap(K) >= K)
   int64_t total_faces;
-  const int* order;  // workgroup -> (mesh * bins + bin), heaviest bins first
+  const int* order;  // workgroup -> (mesh * bins + bin), heaviest bins first; kEmptyBin flags a bin no face box reaches
+  const unsigned* masks;  // face masks of k_project_prep_mesh ([mesh][bin][part][8 words]) or null
+  int parts;              // 256-face parts per mesh (masks only)
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
   // outputs (fragments)
   int32_t* p2f;
@@ -486,11 +527,6 @@ __host__ __device__ inline int64_t layer_counts_offset(int N, int nbx, int nby, 
   return (int64_t)N * nbx * nby * 4 * K * 64 * kRowWords;
 }
 
-__device__ __forceinline__ bool bbox_overlap(const float4 bb, float xc_lo, float xc_hi, float yc_lo, float yc_hi) {
-  // bb = xlo xhi ylo yhi ; reject iff the whole centre interval is on one side of the box
-  return !(xc_hi < bb.x || xc_lo > bb.y || yc_hi < bb.z || yc_lo > bb.w);
-}
-
 // A key packs (depth bits, face index, hides-the-rest flag): unsigned order == (depth, face) order (depths are >= +0).
 __device__ __forceinline__ int key_face(unsigned long long k) { return (int)(((unsigned)(k & 0xffffffffull)) >> 1); }
 
@@ -528,7 +564,10 @@ struct KeyList {
 // MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
 // BIGK (list capacity > 64): the code for lists longer than a wave and for scanning full lists that sit mostly in the spill area
 // -- kept out of the K <= 64 build, whose register allocation it would disturb (1 % on the headline workload)
-template <int MODE, bool BIGK>
+// MASKS (fused mode, equal-sized meshes): the bin's face list comes from the face masks the prep kernel left behind
+// instead of a scan of all the mesh's face boxes: same test, same faces, same order -- 32 bytes per 256 faces to read
+// instead of 256 boxes.
+template <int MODE, bool BIGK, bool MASKS>
 __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BW = 16, BH = 16, WPB = 4;
@@ -548,7 +587,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // workgroup schedule: heaviest bins first (k_bin_order)
-  const int item = P.order[blockIdx.x];
+  const int sched = P.order[blockIdx.x];
+  const int item = sched & kBinIndex;
   const int n = item / (P.nbx * P.nby);
   const int b = item - n * (P.nbx * P.nby);
   const int by = b / P.nbx, bx = b - by * P.nbx;
@@ -622,7 +662,9 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   }
 
   const int64_t f0 = P.eqF > 0 ? (int64_t)n * P.eqF : P.first[n];
-  const int nf = P.eqF > 0 ? P.eqF : (int)P.nfaces[n];
+  // a bin flagged empty by the schedule has no faces to look at: straight to the output (background / padding)
+  const int nf = (sched & kEmptyBin) ? 0 : (P.eqF > 0 ? P.eqF : (int)P.nfaces[n]);
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
 
   for (int rbase = 0; rbase < nf; rbase += kBinCap) {
     // ---- coarse: the round's faces (up to 2048) are split evenly over the waves, wave w scans a contiguous range
@@ -633,24 +675,49 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     const int fbase = (int32_t)f0 + rbase;  // packed index of the round's first face: face = fbase + s_bin[i]
     const int per = ((min(nf - rbase, kBinCap) + 255) >> 8) << 6;  // faces per wave (multiple of 64)
     const int wbase = rbase + wave * per;
-    float4 bbv[kScanQ];
     float zv[kScanQ];
-#pragma unroll
-    for (int q = 0; q < kScanQ; ++q) {
-      const int f = wbase + q * 64 + lane;
-      const bool in = (q * 64 < per) && (f < nf);
-      bbv[q] = in ? P.bbox[f0 + f] : make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
-      zv[q] = (MODE == 2 && in) ? P.fz[f0 + f] : 0.0f;
-    }
     unsigned long long pm[kScanQ];
     int wc = 0;
     float zlo = __builtin_inff(), zhi = -__builtin_inff();
+    if constexpr (MASKS) {
+      // the round's 2048 mask bits: 64 words, one per lane (eight consecutive parts of this bin)
+      const int part0 = rbase >> 8;
+      const int nw = min(8, P.parts - part0) * 8;
+      const unsigned* mp = P.masks + (((int64_t)n * (P.nbx * P.nby) + b) * P.parts + part0) * 8;
+      const unsigned mw = lane < nw ? mp[lane] : 0u;
+      if (__ballot(mw != 0u) == 0ull) continue;  // every wave reads the same words: a uniform decision
 #pragma unroll
-    for (int q = 0; q < kScanQ; ++q) {
-      const bool pass = bbox_overlap(bbv[q], bxc_lo, bxc_hi, byc_lo, byc_hi);
-      pm[q] = __ballot(pass);
-      wc += __popcll(pm[q]);
-      if (MODE == 2 && pass) { zlo = min_s(zlo, zv[q]); zhi = max_s(zhi, zv[q]); }
+      for (int q = 0; q < kScanQ; ++q) {
+        pm[q] = 0ull;
+        zv[q] = 0.0f;
+        if (q * 64 < per) {
+          const int wi = (uwave * per + q * 64) >> 5;
+          pm[q] = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mw, wi) |
+                  ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mw, wi + 1) << 32);
+          if ((pm[q] >> lane) & 1ull) zv[q] = P.fz[f0 + wbase + q * 64 + lane];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kScanQ; ++q) {
+        wc += __popcll(pm[q]);
+        if ((pm[q] >> lane) & 1ull) { zlo = min_s(zlo, zv[q]); zhi = max_s(zhi, zv[q]); }
+      }
+    } else {
+      float4 bbv[kScanQ];
+#pragma unroll
+      for (int q = 0; q < kScanQ; ++q) {
+        const int f = wbase + q * 64 + lane;
+        const bool in = (q * 64 < per) && (f < nf);
+        bbv[q] = in ? P.bbox[f0 + f] : make_float4(__builtin_inff(), -__builtin_inff(), 0.0f, 0.0f);
+        zv[q] = (MODE == 2 && in) ? P.fz[f0 + f] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < kScanQ; ++q) {
+        const bool pass = bbox_overlap(bbv[q], bxc_lo, bxc_hi, byc_lo, byc_hi);
+        pm[q] = __ballot(pass);
+        wc += __popcll(pm[q]);
+        if (MODE == 2 && pass) { zlo = min_s(zlo, zv[q]); zhi = max_s(zhi, zv[q]); }
+      }
     }
     if (MODE == 2) {
       zlo = wave_fmin(zlo);
@@ -1341,31 +1408,53 @@ size_t raster_spill_bytes(int64_t total_faces, int N, int H, int W, int K) {
   return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
 }
 
-template <int MODE, bool BIGK> int launch_raster_k(RasterParams P, hipStream_t st) {
+template <int MODE, bool BIGK, bool MASKS> int launch_raster_k(RasterParams P, hipStream_t st) {
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
   P.KL = list_cap(P.K);
   P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K);
   const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static LdsSlot lds_slot;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE, BIGK>), lds, lds_slot)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE, BIGK, MASKS>), lds, lds_slot)) return rc;
   const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
   {
     ProfScope prof(MODE == 2 ? UR_PROFILE_RASTER_FWD : UR_PROFILE_OTHER, st);
-    hipLaunchKernelGGL((k_raster<MODE, BIGK>), dim3((unsigned)blocks), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((k_raster<MODE, BIGK, MASKS>), dim3((unsigned)blocks), dim3(256), lds, st, P);
   }
   return check_launch("k_raster");
 }
 
 template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
-  if (MODE != 1 && list_cap(P.K) > 64) return launch_raster_k<MODE, true>(P, st);
-  return launch_raster_k<MODE, false>(P, st);
+  if constexpr (MODE == 2) {
+    if (P.masks) {
+      if (list_cap(P.K) > 64) return launch_raster_k<MODE, true, true>(P, st);
+      return launch_raster_k<MODE, false, true>(P, st);
+    }
+  }
+  P.masks = nullptr;
+  if (MODE != 1 && list_cap(P.K) > 64) return launch_raster_k<MODE, true, false>(P, st);
+  return launch_raster_k<MODE, false, false>(P, st);
 }
 
 // workspace = [bbox: NF float4][records: NF x 5 float4][nearest depth: NF float, padded to 16 B]
-//             [schedule: N * bins int, padded to 16 B][bin loads: N * bins int, padded, x prep_parts][K-list spill]
+//             [schedule: N * bins int, padded to 16 B][bin loads: N * bins int, padded, x prep_parts]
+//             [face masks: N * bins * prep_parts x 8 words, where the per-mesh prep kernel can make them][K-list spill]
 size_t sched_ints(int N, int H, int W) { return (((size_t)N * ((H + 15) / 16) * ((W + 15) / 16)) + 3) / 4 * 4; }
+
+// equal-sized meshes of F faces: can the per-mesh prep kernel serve them, and can it leave face masks?
+bool mesh_prep_ok(int64_t F, int H, int W) {
+  return F > 0 && F <= kMeshPrepMaxFaces && (int64_t)((H + 15) / 16) * ((W + 15) / 16) <= kPrepBins;
+}
+bool mesh_masks_ok(int64_t F, int H, int W) {
+  const int nbx = (W + 15) / 16, nby = (H + 15) / 16;
+  return mesh_prep_ok(F, H, W) && nbx * nby <= kMaskBins && nbx <= kMaskAxis && nby <= kMaskAxis;
+}
+size_t mask_words(int64_t NF, int N, int H, int W) {
+  const int64_t F = N > 0 ? (NF + N - 1) / N : 0;
+  if (!mesh_masks_ok(F, H, W)) return 0;
+  return (size_t)N * ((H + 15) / 16) * ((W + 15) / 16) * (size_t)prep_parts(NF, N) * 8;
+}
 
 const int* sched_order(const void* ws, int64_t NF, int N, int H, int W) {
   const float* fz = reinterpret_cast<const float*>(reinterpret_cast<const float4*>(ws) + 6 * NF);
@@ -1373,14 +1462,17 @@ const int* sched_order(const void* ws, int64_t NF, int N, int H, int W) {
 }
 
 // lays the workspace out and points P at its parts
-void carve_workspace(void* ws, int64_t NF, int N, int H, int W, RasterParams& P, int*& binload, int*& order) {
+void carve_workspace(void* ws, int64_t NF, int N, int H, int W, RasterParams& P, int*& binload, int*& order,
+                     unsigned** masks = nullptr) {
   float4* bbox = reinterpret_cast<float4*>(ws);
   float4* rec = bbox + NF;
   float* fz = reinterpret_cast<float*>(rec + 5 * NF);
   order = reinterpret_cast<int*>(fz + ((NF + 3) / 4) * 4);
   binload = order + sched_ints(N, H, W);
   P.bbox = bbox; P.rec = rec; P.fz = fz; P.order = order; P.total_faces = NF;
-  P.spill = reinterpret_cast<unsigned long long*>(binload + sched_ints(N, H, W) * prep_parts(NF, N));
+  unsigned* mk = reinterpret_cast<unsigned*>(binload + sched_ints(N, H, W) * prep_parts(NF, N));
+  if (masks) *masks = mk;
+  P.spill = reinterpret_cast<unsigned long long*>(mk + mask_words(NF, N, H, W));
 }
 
 int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const int64_t* first, int N, int H, int W,
@@ -1595,7 +1687,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   const int H = P.H, W = P.W, K = P.K;
   // same workgroup schedule and pixel ownership as the forward: heaviest bins first; wave w holds every second
   // column / row of the bin from (w & 1, w >> 1)
-  const int item = P.order[blockIdx.x];
+  const int sched = P.order[blockIdx.x];
+  if (sched & kEmptyBin) return;  // no face box reaches the bin: the forward left no rows
+  const int item = sched & kBinIndex;
   const int n = item / (P.nbx * P.nby);
   const int b = item - n * (P.nbx * P.nby);
   const int by = b / P.nbx, bx = b - by * P.nbx;
@@ -2457,7 +2551,7 @@ size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
   const size_t nf = (size_t)(total_faces < 1 ? 1 : total_faces);
   return nf * 96 + ((nf + 3) / 4) * 16 +
          (size_t)(1 + prep_parts(total_faces, N)) * sched_ints(N < 0 ? 0 : N, H, W) * 4 +
-         raster_spill_bytes(total_faces, N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
+         mask_words(total_faces, N < 0 ? 0 : N, H, W) * 4 + raster_spill_bytes(total_faces, N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
 }
 
 int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
@@ -2783,19 +2877,23 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
   hipStream_t st = (hipStream_t)stream;
   const int nbins = ((H + 15) / 16) * ((W + 15) / 16);
   const int64_t n_gfv = (int64_t)F * 9, n_gmap = (int64_t)Ht * Wt * 3;
-  if (F > 0 && F <= kMeshPrepMaxFaces && nbins <= kPrepBins && n_gfv <= 0x7fffffffLL && n_gmap <= 0x7fffffffLL &&
-      N <= 0x7fffffff / nbins && N <= 65535) {
+  if (mesh_prep_ok(F, H, W) && n_gfv <= 0x7fffffffLL && n_gmap <= 0x7fffffffLL && N <= 0x7fffffff / nbins &&
+      N <= 65535) {
     const size_t need = ur_workspace_bytes(NF, N, H, W, K);
     if (workspace_bytes < need) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))
       return fail(UR_ERR_WORKSPACE, "workspace must be 16-byte aligned");
     int* binload = nullptr;
     int* order = nullptr;
-    carve_workspace(workspace, NF, N, H, W, P, binload, order);
+    unsigned* masks = nullptr;
+    carve_workspace(workspace, NF, N, H, W, P, binload, order, &masks);
     const int parts = prep_parts(NF, N);
+    if (!mesh_masks_ok(F, H, W)) masks = nullptr;
+    P.masks = masks;
+    P.parts = parts;
     hipLaunchKernelGGL(k_project_prep_mesh, dim3((unsigned)parts, (unsigned)N), dim3(256), 0, st, verts, faces, faces_mesh_stride, R, T,
                        sx, sy, N, V, F, sqrtf(blur_radius), cull_backfaces, H, W, face_verts, const_cast<float4*>(P.bbox),
-                       const_cast<float4*>(P.rec), const_cast<float*>(P.fz), binload, zero_grad_face_verts, (int)n_gfv,
+                       const_cast<float4*>(P.rec), const_cast<float*>(P.fz), binload, masks, zero_grad_face_verts, (int)n_gfv,
                        zero_grad_maps, (int)n_gmap);
     rc = check_launch("k_project_prep_mesh");
     if (rc) return rc;
