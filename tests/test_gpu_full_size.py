@@ -147,3 +147,31 @@ def test_stress_config_256px_k100_ico5():
     cot = np.random.RandomState(3).randn(*out.shape).astype(np.float32)
     g = b.grads(torch.from_numpy(cot).to(DEV))
     b.check_against_oracle(out, g, cot, picks=(1,))
+
+
+def test_stress_config_at_shard_size_b128():
+    """configs[4] at the size one GPU of the node holds (1024 meshes over 8 GPUs): B=128 meshes of 20480 faces,
+    256x256, K=100 -- ~27 GB of layer rows, ~7 GB of K-list spill, 2.6 M faces through the per-mesh prep kernel (80
+    parts per mesh) and its face masks.  Whole batch: determinism and batch independence of image and gradients;
+    one image against the oracle, forward and backward."""
+    b = Batch(128, 5, 256, 100, seed=11)
+    out = b.render().detach()
+    assert out.shape == (128, 4, 256, 256)
+    assert torch.equal(out, b.render().detach())
+    assert torch.equal(out[100:102], b.render(slice(100, 102)).detach())
+    assert torch.equal(out[100:102], b.render(slice(100, 102), fused=False).detach())  # fused == two-stage
+    a = out[:, 3]
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 and 0.05 < float(a.mean()) < 0.9
+    cot = np.random.RandomState(5).randn(*out.shape).astype(np.float32)
+    g = b.grads(torch.from_numpy(cot).to(DEV))
+    assert all(bool(torch.isfinite(x).all()) for x in g)
+    # gradients of mesh n depend on image n only: the same mesh rendered on its own
+    sl = slice(77, 78)
+    b.rend.renderer.fused = True
+    for t in b.leaves:
+        t.grad = None
+    b.render(sl).backward(torch.from_numpy(cot[sl]).to(DEV))
+    alone = [t.grad[sl].detach().clone() for t in b.leaves]
+    errs = [rel_err(x.cpu().numpy(), y[sl].cpu().numpy()) for x, y in zip(alone, g)]
+    assert max(errs) <= 1e-4, errs
+    b.check_against_oracle(out, g, cot, picks=(77,))
