@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--img", type=int, default=64)
     a = ap.parse_args()
     rank, local, world = udist.env_world()
+    if world > 1:
+        udist.isolate_miopen_cache(rank)                  # before the first convolution: no shared kernel-cache locks
     torch.cuda.set_device(local)
     udist.init("nccl")
     dev = torch.device("cuda", local)

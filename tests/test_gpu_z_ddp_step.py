@@ -27,17 +27,24 @@ def _make(device):
 
 
 def _rank_main(rank, world, port, out_path):
+    import faulthandler
+    import time
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     from examples.train_step import train_steps
+    from unicorn_amd import dist as udist
+    # a rank that is still busy after 80 s says where (all threads) before the parent's limit kills it
+    faulthandler.dump_traceback_later(80, exit=False)
+    udist.isolate_miopen_cache(rank)  # the ranks share the box: each gets its own MIOpen database / kernel cache
+    t0 = time.perf_counter()
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.backends.cudnn.enabled = False  # see the test: no MIOpen kernel builds in processes that share a box
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     model, imgs = _make(dev)
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
     losses = train_steps(ddp, imgs[rank * PER_RANK:(rank + 1) * PER_RANK], STEPS)
+    print(f"rank {rank}: {STEPS} DDP steps (MIOpen convolutions) after {time.perf_counter() - t0:.1f} s", flush=True)
     t = torch.tensor(losses, device=dev)
     dist.all_reduce(t)
     if rank == 0:
@@ -45,6 +52,7 @@ def _rank_main(rank, world, port, out_path):
                     "losses": (t / world).cpu()}, out_path)
     dist.barrier()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 def test_two_rank_ddp_step_equals_single_process_training():
@@ -61,16 +69,9 @@ def test_two_rank_ddp_step_equals_single_process_training():
             for p in ctx.processes:
                 p.kill()
             pytest.fail("DDP ranks did not finish within 100 s")
-        # the same training in this process on the whole batch (after the ranks).  The encoder's convolutions run
-        # without MIOpen here and in the ranks: processes building MIOpen kernels at the same time on a fresh box were
-        # seen to stall each other for minutes (kernel-database locks), and the test is about the renderer under DDP
-        was = torch.backends.cudnn.enabled
-        torch.backends.cudnn.enabled = False
-        try:
-            model, imgs = _make(torch.device("cuda", 0))
-            losses = train_steps(model, imgs, STEPS)
-        finally:
-            torch.backends.cudnn.enabled = was
+        # the same training in this process on the whole batch (after the ranks), MIOpen convolutions on both sides
+        model, imgs = _make(torch.device("cuda", 0))
+        losses = train_steps(model, imgs, STEPS)
         got = torch.load(out_path, weights_only=True)
     np.testing.assert_allclose(got["losses"].numpy(), np.array(losses), rtol=1e-4)
     assert losses[-1] < losses[0]

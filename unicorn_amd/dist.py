@@ -14,6 +14,19 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def isolate_miopen_cache(rank):
+    """Give this process its own MIOpen user database and kernel cache directory (unless the caller already chose
+    them).  MIOpen keeps both under ~/.config/miopen and ~/.cache/miopen behind file locks; ranks that meet a new
+    convolution shape at the same moment -- every rank of a DDP job does, on a box that has never run it -- then queue
+    on those locks while each tunes / builds the same kernels.  Must run before the process's first convolution."""
+    base = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"miopen-{os.getuid()}", f"rank{int(rank)}")
+    for var, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+        if var not in os.environ:
+            path = os.path.join(base, sub)
+            os.makedirs(path, exist_ok=True)
+            os.environ[var] = path
+
+
 def init(backend=None):
     """-> (rank, local_rank, world).  backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU."""
     rank, local, world = env_world()
