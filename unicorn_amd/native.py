@@ -123,26 +123,47 @@ def _ptr(t, dtype=None, allow_none=False):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    """torch's current HIP stream on t's device, as the raw handle the C ABI takes"""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
 class _on:
-    """`with _on(t):` = make t's GPU current, after checking that t lives on one."""
+    """`with _on(t):` = make t's GPU current, after checking that t lives on one.  When it is current already (the
+    usual case: one process per GPU) nothing is switched."""
 
     def __init__(self, t):
         _ptr(t)
-        self._ctx = torch.cuda.device(t.device)
+        self._ctx = None if t.device.index == torch.cuda.current_device() else torch.cuda.device(t.device)
 
     def __enter__(self):
-        return self._ctx.__enter__()
+        if self._ctx is not None:
+            self._ctx.__enter__()
 
     def __exit__(self, *a):
-        return self._ctx.__exit__(*a)
+        if self._ctx is not None:
+            self._ctx.__exit__(*a)
+
+
+_size_cache = {}
+
+
+def _sized(fn_name, *args):
+    """a size query of the library (pure functions of their integer arguments), asked once per argument tuple"""
+    key = (fn_name,) + args
+    v = _size_cache.get(key)
+    if v is None:
+        v = _size_cache[key] = int(getattr(lib(), fn_name)(*args))
+    return v
 
 
 def workspace_bytes(total_faces, N, H, W, K):
-    return int(lib().ur_workspace_bytes(int(total_faces), int(N), int(H), int(W), int(K)))
+    return _sized("ur_workspace_bytes", int(total_faces), int(N), int(H), int(W), int(K))
 
 
 def _workspace(total_faces, device, N, H, W, K):
@@ -263,8 +284,20 @@ def tile_faces(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_rad
     return counts, lists
 
 
+_rgb_cache = {}
+
+
 def _rgb(v):
-    return None if v is None else _F3(*[float(x) for x in v])
+    """three floats as a C array (kept per distinct colour: the arrays are read-only inputs of the calls)"""
+    if v is None:
+        return None
+    key = tuple(v) if not isinstance(v, tuple) else v
+    a = _rgb_cache.get(key)
+    if a is None:
+        if len(_rgb_cache) > 256:
+            _rgb_cache.clear()
+        a = _rgb_cache[key] = _F3(*[float(x) for x in key])
+    return a
 
 
 def shade_blend(pix_to_face, bary, dists, maps, face_uvs, face_uvs_shared, mesh_first_face, sigma, background,
@@ -339,7 +372,7 @@ def render_layered_forward(face_verts, mesh_first_face, mesh_num_faces, image_si
     Ht, Wt = maps.shape[1:3]
     dev = face_verts.device
     image = torch.empty(N, 4, H, W, dtype=torch.float32, device=dev)
-    layers = torch.empty(int(lib().ur_layers_elems(N, H, W, K)), dtype=torch.int32, device=dev)
+    layers = torch.empty(_sized("ur_layers_elems", N, H, W, K), dtype=torch.int32, device=dev)
     ws = _workspace(NF, dev, N, H, W, K)
     with _on(face_verts), _timed("ur_render_layered_forward", face_verts):
         _check(lib().ur_render_layered_forward(
@@ -365,7 +398,7 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
     zeros = torch.zeros(n_fv_pad + (maps.numel() if need_maps else 0), dtype=torch.float32, device=dev)
     gfv = zeros[:n_fv].view(total_faces, 3, 3) if need_face_verts else None
     gmaps = zeros[n_fv_pad:].view(maps.shape) if need_maps else None
-    scratch = torch.empty(int(lib().ur_backward_scratch_bytes(N, H, W, K)), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(_sized("ur_backward_scratch_bytes", N, H, W, K), dtype=torch.uint8, device=dev)
     with _on(maps), _timed("ur_render_layered_backward", maps):
         _check(lib().ur_render_layered_backward(
             _ptr(grad_image, torch.float32), _ptr(mesh_first_face, torch.int64), _ptr(mesh_num_faces, torch.int64), N,
@@ -379,7 +412,7 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
 
 
 def _rgb_ptr(v):
-    return None if v is None else ctypes.cast(_rgb(v), _vp)
+    return None if v is None else ctypes.addressof(_rgb(v))
 
 
 def render_meshes_forward(verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_faces, image_size, blur_radius,
@@ -396,7 +429,7 @@ def render_meshes_forward(verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_
     NF = N * F
     face_verts = torch.empty(NF, 3, 3, dtype=torch.float32, device=dev)
     image = torch.empty(N, 4, H, W, dtype=torch.float32, device=dev)
-    layers = torch.empty(int(lib().ur_layers_elems(N, H, W, K)), dtype=torch.int32, device=dev)
+    layers = torch.empty(_sized("ur_layers_elems", N, H, W, K), dtype=torch.int32, device=dev)
     ws = _workspace(NF, dev, N, H, W, K)
     grads = gfv = gmaps = None
     if need_geometry_grads or need_map_grads:
@@ -439,7 +472,7 @@ def render_meshes_backward(grad_image, verts, faces, R, T, sx, sy, mesh_first_fa
     gv = torch.empty_like(verts) if need_verts else None
     gR = torch.empty_like(R) if need_R else None
     gT = torch.empty_like(T) if need_T else None
-    scratch = torch.empty(int(lib().ur_backward_scratch_bytes(N, H, W, K)), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(_sized("ur_backward_scratch_bytes", N, H, W, K), dtype=torch.uint8, device=dev)
     with _on(verts), _timed("ur_render_meshes_backward", verts):
         _check(lib().ur_render_meshes_backward(
             _ptr(grad_image, torch.float32), _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,

@@ -81,6 +81,12 @@ class PointLights(AmbientLights):
 def _rgb3(c):
     """colour given as tuple / nested list / tensor -> 3 python floats, without touching the GPU stream unless the
     caller stored a device tensor"""
+    if not torch.is_tensor(c):  # plain numbers (the configs' case): no tensor round trip
+        flat = c
+        while isinstance(flat, (tuple, list)) and len(flat) == 1:
+            flat = flat[0]
+        if isinstance(flat, (tuple, list)) and len(flat) == 3 and all(isinstance(v, (int, float)) for v in flat):
+            return (float(flat[0]), float(flat[1]), float(flat[2]))
     t = torch.as_tensor(c, dtype=torch.float32).detach().cpu().flatten()
     assert t.numel() == 3, "colour must have 3 components"
     return tuple(float(v) for v in t)
