@@ -496,6 +496,12 @@ struct RasterParams {
   const float* gimage;
   float* gmaps;
   float* gfv;
+  // fused backward over equal-sized meshes (one-call path): sum_V > 0 makes the kernel add a face's corner gradients
+  // straight into per-VERTEX sums (x, y of vertex v of mesh n at gfv[(n * sum_V + v) * 2 ...], the buffer being the
+  // grad_face_verts allocation) through the faces table, so that the camera's backward has nothing left to gather
+  int sum_V;
+  const int64_t* faces;
+  int64_t fstride;
 };
 
 // face-UV table row of packed face `fid` of mesh n
@@ -1475,6 +1481,13 @@ void carve_workspace(void* ws, int64_t NF, int N, int H, int W, RasterParams& P,
   P.spill = reinterpret_cast<unsigned long long*>(mk + mask_words(NF, N, H, W));
 }
 
+// Equal-sized meshes: does the one-call forward go through the per-mesh prep kernel?
+bool one_call_prep(int N, int V, int F, int H, int W, int Ht, int Wt) {
+  const int64_t nbins = (int64_t)((H + 15) / 16) * ((W + 15) / 16);
+  return mesh_prep_ok(F, H, W) && (int64_t)F * 9 <= 0x7fffffffLL && (int64_t)Ht * Wt * 3 <= 0x7fffffffLL &&
+         N <= 0x7fffffff / nbins && N <= 65535;
+}
+
 int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const int64_t* first, int N, int H, int W,
                int K, void* ws, size_t ws_bytes, hipStream_t st, RasterParams& P) {
   const size_t need = ur_workspace_bytes(NF, N, H, W, K);
@@ -1680,17 +1693,24 @@ template <int kFaceSlots, int kTexCols>
 __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   constexpr int kTexSlots = 16 * kTexCols;
   __shared__ int s_ftag[kFaceSlots];
-  __shared__ double s_fval[kFaceSlots * 6];
   __shared__ int s_ttag[kTexSlots];
+  __shared__ double s_fval[kFaceSlots * 6];
   __shared__ double s_tval[kTexSlots * 3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = P.H, W = P.W, K = P.K;
   // same workgroup schedule and pixel ownership as the forward: heaviest bins first; wave w holds every second
   // column / row of the bin from (w & 1, w >> 1)
   const int sched = P.order[blockIdx.x];
-  if (sched & kEmptyBin) return;  // no face box reaches the bin: the forward left no rows
   const int item = sched & kBinIndex;
   const int n = item / (P.nbx * P.nby);
+  // where component c (corner c >> 1, x / y) of face `fid` is summed: its slot of grad_face_verts, or -- in the
+  // one-call path -- the x / y sum of the vertex at that corner ([mesh][vertex][2])
+  auto face_sum = [&](int fid, int c) -> float* {
+    if (P.sum_V <= 0) return P.gfv + (int64_t)fid * 9 + (c >> 1) * 3 + (c & 1);
+    const int64_t vid = P.faces[(int64_t)n * P.fstride + (int64_t)(fid - n * P.eqF) * 3 + (c >> 1)];
+    return P.gfv + (((int64_t)n * P.sum_V + vid) << 1) + (c & 1);
+  };
+  if (sched & kEmptyBin) return;  // no face box reaches the bin: the forward left no rows
   const int b = item - n * (P.nbx * P.nby);
   const int by = b / P.nbx, bx = b - by * P.nbx;
   const int tx0 = bx * 16 + (wave & 1), ty0 = by * 16 + (wave >> 1);
@@ -1881,10 +1901,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
           for (int i = 0; i < 6; ++i)
             if (o[i] != 0.0f) atomicAdd(&s_fval[h * 6 + i], (double)o[i]);
         } else {
-          float* gf = P.gfv + (int64_t)fid * 9;
 #pragma unroll
           for (int i = 0; i < 6; ++i)
-            if (o[i] != 0.0f) atomicAdd(gf + (i >> 1) * 3 + (i & 1), o[i]);
+            if (o[i] != 0.0f) atomicAdd(face_sum(fid, i), o[i]);
         }
       }
     }
@@ -1896,7 +1915,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       const int slot = i / 6, c = i - slot * 6;
       const int tag = s_ftag[slot];
       const float v = (float)s_fval[i];
-      if (tag >= 0 && v != 0.0f) atomicAdd(P.gfv + (int64_t)tag * 9 + (c >> 1) * 3 + (c & 1), v);
+      if (tag >= 0 && v != 0.0f) atomicAdd(face_sum(tag, c), v);
     }
   if (gmap)
     for (int i = tid; i < kTexSlots * 3; i += 256) {
@@ -2148,6 +2167,54 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
     if (dst) {
       if (gridDim.y == 1) *dst = v; else atomicAdd(dst, v);
     }
+  }
+}
+
+// The camera's backward from per-VERTEX sums of the NDC x / y gradients (the fused backward's one-call mode leaves
+// them as [mesh][vertex][2]; the layered blend never reads depth, so there is no z term): the per-vertex half of
+// k_project_faces_bwd_mesh, same arithmetic, nothing to gather.  One workgroup per mesh.
+__global__ void __launch_bounds__(1024) k_camera_bwd_mesh(const float* __restrict__ verts, const float* __restrict__ R,
+                                                          const float* __restrict__ T, float sx, float sy, int V,
+                                                          const float2* __restrict__ vsum, float* __restrict__ gverts,
+                                                          float* __restrict__ gR, float* __restrict__ gT) {
+  __shared__ float part[16 * 12];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* r = R + (int64_t)n * 9;
+  const float* t = T + (int64_t)n * 3;
+  float s[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) s[q] = 0.0f;
+  for (int v = tid; v < V; v += 1024) {
+    const float* p = verts + ((int64_t)n * V + v) * 3;
+    const float2 g = vsum[(int64_t)n * V + v];
+    const float g0 = g.x, g1 = g.y, g2 = 0.0f;
+    const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
+    const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
+    const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
+    const float gv[3] = {g0 * sx / vz, g1 * sy / vz, g2 - (g0 * sx * vx + g1 * sy * vy) / (vz * vz)};
+    if (gverts) {
+      float* go = gverts + ((int64_t)n * V + v) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) go[i] = gv[0] * r[i * 3 + 0] + gv[1] * r[i * 3 + 1] + gv[2] * r[i * 3 + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s[i * 3 + j] += p[i] * gv[j];
+    s[9] += gv[0]; s[10] += gv[1]; s[11] += gv[2];
+  }
+  if (!gR && !gT) return;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    const float v = wave_sum(s[q]);
+    if ((tid & 63) == 63) part[(tid >> 6) * 12 + q] = v;
+  }
+  __syncthreads();
+  if (tid < 12) {
+    float v = 0.0f;
+    for (int w = 0; w < 16; ++w) v += part[w * 12 + tid];
+    float* dst = tid < 9 ? (gR ? gR + (int64_t)n * 9 + tid : nullptr) : (gT ? gT + (int64_t)n * 3 + tid - 9 : nullptr);
+    if (dst) *dst = v;
   }
 }
 
@@ -2810,7 +2877,8 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
                             const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
                             const float* background, const float* ambient, int mode, const int32_t* layers,
                             const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
-                            float* grad_face_verts, float* grad_maps, void* stream, int eqF) {
+                            float* grad_face_verts, float* grad_maps, void* stream, int eqF, int sum_V = 0,
+                            const int64_t* faces = nullptr, int64_t fstride = 0) {
   if (!grad_image || !layers || !workspace || !scratch) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (scratch_bytes < ur_backward_scratch_bytes(N, H, W, K)) return fail(UR_ERR_WORKSPACE, "scratch too small");
   if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
@@ -2827,6 +2895,7 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
   P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
   P.scratch = reinterpret_cast<float*>(scratch);
   P.eqF = eqF;
+  if (sum_V > 0 && grad_face_verts && faces) { P.sum_V = sum_V; P.faces = faces; P.fstride = fstride; }
   P.nbx = (W + 15) / 16;
   P.nby = (H + 15) / 16;
   const int64_t blocks = (int64_t)N * P.nbx * P.nby;
@@ -2877,8 +2946,7 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
   hipStream_t st = (hipStream_t)stream;
   const int nbins = ((H + 15) / 16) * ((W + 15) / 16);
   const int64_t n_gfv = (int64_t)F * 9, n_gmap = (int64_t)Ht * Wt * 3;
-  if (mesh_prep_ok(F, H, W) && n_gfv <= 0x7fffffffLL && n_gmap <= 0x7fffffffLL && N <= 0x7fffffff / nbins &&
-      N <= 65535) {
+  if (one_call_prep(N, V, F, H, W, Ht, Wt)) {
     const size_t need = ur_workspace_bytes(NF, N, H, W, K);
     if (workspace_bytes < need) return fail(UR_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))
@@ -2936,11 +3004,21 @@ int ur_render_meshes_backward(const float* grad_image, const float* verts, const
     if (grad_maps && hipMemsetAsync(grad_maps, 0, (size_t)N * Ht * Wt * 12, st) != hipSuccess)
       return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
   }
+  // One-call path: the fused kernel adds into per-vertex sums (kept in the grad_face_verts buffer, which they must
+  // fit), so the camera's backward is a per-vertex pass with nothing to gather (k_camera_bwd_mesh).
+  const bool vsum = geometry && N > 0 && F > 0 && V > 0 && verts && faces && R && T && (int64_t)V * 2 <= (int64_t)F * 9;
   int rc = layered_backward(grad_image, mesh_first_face, mesh_num_faces, N, NF, H, W, blur_radius, K,
                             clip_barycentric_coords, maps, face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient,
                             mode, layers, workspace, workspace_bytes, scratch, scratch_bytes,
-                            geometry ? grad_face_verts : nullptr, grad_maps, stream, F);
+                            geometry ? grad_face_verts : nullptr, grad_maps, stream, F, vsum ? V : 0, faces,
+                            faces_mesh_stride);
   if (rc || !geometry) return rc;
+  if (vsum) {
+    if (N > 65535) return fail(UR_ERR_INVALID_ARG, "too many meshes per call");
+    hipLaunchKernelGGL(k_camera_bwd_mesh, dim3((unsigned)N), dim3(1024), 0, st, verts, R, T, sx, sy, V,
+                       reinterpret_cast<const float2*>(grad_face_verts), grad_verts, grad_R, grad_T);
+    return check_launch("k_camera_bwd_mesh");
+  }
   return ur_project_faces_backward(verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts, grad_verts,
                                    grad_R, grad_T, stream);
 }
