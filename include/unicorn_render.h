@@ -228,17 +228,20 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
  * in one call each way: camera + face gather + rasterizer + shader.
  * Replaces: MeshRenderer.forward (renderer.py:48-49: MeshRasterizer.transform + rasterize_meshes + LayeredShader) as
  *           called by Renderer.forward (renderer.py:80-81), and its autograd (trainer.py:151).
- * Same numbers as ur_project_faces + ur_render_layered_forward (bit for bit) and their backwards.  Up to 8192 faces
- * per mesh everything before the rasterizer is ONE launch (one workgroup per mesh: projection, face records, per-bin
- * load in LDS, per-mesh schedule interleaved across meshes -- no global atomics, nothing to pre-zero); larger meshes
- * go through the per-face kernels inside the same call.
+ * Same numbers as ur_project_faces + ur_render_layered_forward (bit for bit) and their backwards.  Up to 32768 faces
+ * per mesh everything before the schedule is ONE launch (a workgroup per 256 faces of a mesh: projection, face records,
+ * per-bin load and 256-bit face masks in LDS -- no global atomics, nothing to pre-zero; the rasterizer then takes a
+ * bin's face list from the masks instead of scanning the mesh's boxes); larger meshes go through the per-face kernels
+ * inside the same call.
  *   verts (N,V,3), faces / faces_mesh_stride as in ur_project_faces, mesh_first_face[n] = n*F, mesh_num_faces[n] = F ;
  *   face_verts (N*F,3,3): OUTPUT (the projected corners; the caller may want them, the backward does not) ;
  *   zero_grad_face_verts (N*F,3,3) / zero_grad_maps (N,Ht,Wt,3): optional buffers the forward clears on the way, to be
  *   handed to ur_render_meshes_backward with grads_are_zero = 1 (saves the backward a fill launch); NULL = skip.
  * Backward: grad_image (N,4,H,W) -> grad_maps (N,Ht,Wt,3), grad_verts (N,V,3), grad_R (N,3,3), grad_T (N,3); any may
- *   be NULL.  grad_face_verts (N*F,3,3) is the intermediate accumulator (needed when any of grad_verts / grad_R /
- *   grad_T is wanted).  grads_are_zero = 0 makes the call clear grad_face_verts and grad_maps itself.
+ *   be NULL.  grad_face_verts (N*F,3,3 floats) is the intermediate accumulator (needed when any of grad_verts /
+ *   grad_R / grad_T is wanted); its contents after the call are unspecified (this call keeps per-vertex sums in it,
+ *   not per-corner gradients: use ur_render_layered_backward for those).  grads_are_zero = 0 makes the call clear
+ *   grad_face_verts and grad_maps itself.
  *   layers / workspace: what the forward left; scratch: ur_backward_scratch_bytes() of uninitialised memory.
  */
 int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
