@@ -470,6 +470,7 @@ struct RasterParams {
   const unsigned* masks;  // face masks of k_project_prep_mesh ([mesh][bin][part][8 words]) or null
   int parts;              // 256-face parts per mesh (masks only)
   unsigned long long* spill;  // [tiles][K-cap][64] overflow of the K-lists
+  unsigned long long* full_thr;  // fused mode: [tiles][64] largest key of a pixel's list once it is full (see the pair route)
   // outputs (fragments)
   int32_t* p2f;
   float* zbuf;
@@ -567,6 +568,50 @@ struct KeyList {
   }
 };
 
+// Fused mode, lists that are FULL (KL entries): the lanes in `pending` each hold a hit (key, pixel) that found its
+// pixel's list full.  One at a time, all 64 lanes scan that list for its two largest entries; the newcomer replaces the
+// largest if it beats it (the exact keep-the-KL-smallest rule, whatever the order of arrival), and the list's new
+// largest key is left in thr[pixel] so that later candidates that cannot improve the list are dropped unseen.
+__device__ __attribute__((noinline)) void full_list_insert(unsigned long long pending, unsigned long long over_key,
+                                                           int over_pl, unsigned long long* lds_keys,
+                                                           unsigned long long* spill_keys, unsigned long long* thr,
+                                                           int cap, int KL) {
+  const int lane = threadIdx.x & 63;
+  while (pending) {
+    const int srcl = __builtin_ctzll(pending);
+    pending &= pending - 1;
+    const int opl = __builtin_amdgcn_readlane(over_pl, srcl);
+    const unsigned long long okey =
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(over_key >> 32), srcl) << 32) |
+        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)over_key, srcl);
+    unsigned long long m1 = 0ull, m2 = 0ull;
+    int i1 = 0;
+    for (int j = lane; j < KL; j += 64) {
+      const unsigned long long v = j < cap ? lds_keys[(size_t)j * 64 + opl] : spill_keys[(size_t)(j - cap) * 64 + opl];
+      if (v > m1) { m2 = m1; m1 = v; i1 = j; }
+      else if (v > m2) m2 = v;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {  // the wave's two largest (keys are unique)
+      const unsigned long long o1 = __shfl_xor(m1, d, 64), o2 = __shfl_xor(m2, d, 64);
+      const int oi = __shfl_xor(i1, d, 64);
+      const unsigned long long lo = o1 < m1 ? o1 : m1;  // the smaller of the two maxima
+      if (o1 > m1) { m1 = o1; i1 = oi; }
+      m2 = m2 > o2 ? m2 : o2;
+      m2 = m2 > lo ? m2 : lo;
+    }
+    if (lane == 0) {
+      unsigned long long largest = m1;
+      if (okey < m1) {
+        if (i1 < cap) lds_keys[(size_t)i1 * 64 + opl] = okey;
+        else spill_keys[(size_t)(i1 - cap) * 64 + opl] = okey;
+        largest = okey > m2 ? okey : m2;
+      }
+      thr[opl] = largest;
+    }
+  }
+}
+
 // MODE 0: write fragments ; MODE 1: export tile lists ; MODE 2: fused UV sampling + layered blend (image + layers)
 // BIGK (list capacity > 64): the code for lists longer than a wave and for scanning full lists that sit mostly in the spill area
 // -- kept out of the K <= 64 build, whose register allocation it would disturb (1 % on the headline workload)
@@ -655,9 +700,13 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   int compact_at = 0;                  // wave-uniform: longest list at which the next in-loop compaction is due (0: the LDS cap)
   float pxc[8], pyc[8];                // the tile's 8 column / 8 row centres (wave-uniform)
   unsigned livecols = 0, liverows = 0;
+  // a full list's largest key (all ones while the list is not full): candidates that do not beat it are dropped
+  // without a look at the list
+  unsigned long long* const thr_keys = (MODE == 2) ? P.full_thr + (tile_live ? tile_id : 0) * 64 : nullptr;
   if (MODE == 2) {
     s_cnt[lane] = 0;
     s_hide[lane] = ~0ull;
+    if (tile_live) thr_keys[lane] = ~0ull;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       pxc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), j));
@@ -971,34 +1020,28 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 const int mx = __builtin_amdgcn_readfirstlane(wave_max(need ? c2 : 0));
                 const int j = keys.compact(need, c2, mx, hk);
                 full_known = 0;
-                if (need) { c2 = j; s_cnt[lane] = c2; }
+                if (need) {
+                  if (j < c2 && c2 >= KL) thr_keys[lane] = ~0ull;  // no longer full: the old largest key says nothing
+                  c2 = j;
+                  s_cnt[lane] = c2;
+                }
                 last_hk = hk;
                 any_stale = false;
                 cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
                 compact_at = cmax < lim ? 0 : min(KL, 2 * cmax);
               }
-              const int room = KL - cmax;
-              if (room < min(nfp - r0, 4)) {
-                const int r1 = min(nfp, r0 + 8);
-                cnt = c2;
-                hide_key = s_hide[lane];
-                z_hide = (hide_key == ~0ull) ? __builtin_inff() : __uint_as_float((unsigned)(hide_key >> 32));
-                stale = hide_key != last_hk;
-                for (int r = r0; r < r1; ++r)
-                  lockstep_face(c, __builtin_amdgcn_readlane((int)cinfo, r) & 63, bbs, rcs);
-                s_cnt[lane] = cnt;
-                s_hide[lane] = hide_key;
-                if (!stale) last_hk = hide_key;
-                any_stale = any_stale || __any(stale);
-                r0 = r1;
-                continue;
-              }
-              const int r1 = r0 + min(nfp - r0, room);
+              // Every face goes the pair way.  A hit on a FULL list (KL entries) is kept in its lane's registers
+              // until the batch is through; the wave then takes those hits one by one, all 64 lanes scanning the
+              // pixel's list together for its two largest entries: the newcomer replaces the largest if it beats it
+              // -- the exact keep-the-KL-smallest rule, whatever the order -- and the list's new largest key is
+              // remembered, so that later candidates that cannot improve the list cost nothing.
+              const int r1 = nfp;
               const int pbeg = __builtin_amdgcn_readlane(cpre, r0), pend = __builtin_amdgcn_readlane(cend, r1 - 1);
               bool improved = false;
               for (int pb = pbeg; pb < pend; pb += 64) {
                 const int pidx = pb + lane;
                 const bool act = pidx < pend;
+                unsigned long long over_key = ~0ull;  // this lane's hit on a full list, if any (handled after the batch)
                 // which face does pair pidx belong to?  The faces that start inside the batch mark their first
                 // pair's slot with their rank + 1, slot 0 takes the face that holds pair pb, and a running maximum
                 // spreads the marks to the right.
@@ -1031,11 +1074,20 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                     if (hides && key < hk) { atomicMin(&s_hide[pl], key); hk = key; improved = true; }
                     if (key <= hk) {
                       const int slot = atomicAdd(&s_cnt[pl], 1);
-                      if (slot < P.cap) lds_keys[(size_t)slot * 64 + pl] = key;
-                      else spill_keys[(size_t)(slot - P.cap) * 64 + pl] = key;
+                      if (slot < KL) {
+                        if (slot < P.cap) lds_keys[(size_t)slot * 64 + pl] = key;
+                        else spill_keys[(size_t)(slot - P.cap) * 64 + pl] = key;
+                      } else {
+                        atomicSub(&s_cnt[pl], 1);  // the list is full
+                        if (key < thr_keys[pl]) over_key = key;
+                      }
                     }
                   }
                 }
+                // hits on full lists, one at a time, the whole wave on each (out of line: rare, and its registers would
+                // otherwise count against the loop above)
+                const unsigned long long pending = __ballot(over_key != ~0ull);
+                if (pending) full_list_insert(pending, over_key, pl, lds_keys, spill_keys, thr_keys, P.cap, KL);
               }
               any_stale = any_stale || __any(improved);
               r0 = r1;
@@ -1409,6 +1461,9 @@ int raster_cap(int64_t total_faces, int N, int H, int W, int K) {
   return KL < fit ? KL : fit;
 }
 
+// largest-key words of full lists: one per pixel of every 64-pixel group (fused mode)
+size_t full_thr_bytes(int N, int H, int W) { return (size_t)(N < 0 ? 0 : N) * wave_groups(H, W) * 64 * 8; }
+
 size_t raster_spill_bytes(int64_t total_faces, int N, int H, int W, int K) {
   const int over = list_cap(K) - raster_cap(total_faces, N, H, W, K);
   return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
@@ -1445,7 +1500,8 @@ template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
 
 // workspace = [bbox: NF float4][records: NF x 5 float4][nearest depth: NF float, padded to 16 B]
 //             [schedule: N * bins int, padded to 16 B][bin loads: N * bins int, padded, x prep_parts]
-//             [face masks: N * bins * prep_parts x 8 words, where the per-mesh prep kernel can make them][K-list spill]
+//             [face masks: N * bins * prep_parts x 8 words, where the per-mesh prep kernel can make them]
+//             [largest keys of full K-lists: 64 x u64 per 64-pixel group][K-list spill]
 size_t sched_ints(int N, int H, int W) { return (((size_t)N * ((H + 15) / 16) * ((W + 15) / 16)) + 3) / 4 * 4; }
 
 // equal-sized meshes of F faces: can the per-mesh prep kernel serve them, and can it leave face masks?
@@ -1478,7 +1534,8 @@ void carve_workspace(void* ws, int64_t NF, int N, int H, int W, RasterParams& P,
   P.bbox = bbox; P.rec = rec; P.fz = fz; P.order = order; P.total_faces = NF;
   unsigned* mk = reinterpret_cast<unsigned*>(binload + sched_ints(N, H, W) * prep_parts(NF, N));
   if (masks) *masks = mk;
-  P.spill = reinterpret_cast<unsigned long long*>(mk + mask_words(NF, N, H, W));
+  P.full_thr = reinterpret_cast<unsigned long long*>(mk + mask_words(NF, N, H, W));
+  P.spill = P.full_thr + full_thr_bytes(N, H, W) / 8;
 }
 
 // Equal-sized meshes: does the one-call forward go through the per-mesh prep kernel?
@@ -2618,7 +2675,7 @@ size_t ur_workspace_bytes(int64_t total_faces, int N, int H, int W, int K) {
   const size_t nf = (size_t)(total_faces < 1 ? 1 : total_faces);
   return nf * 96 + ((nf + 3) / 4) * 16 +
          (size_t)(1 + prep_parts(total_faces, N)) * sched_ints(N < 0 ? 0 : N, H, W) * 4 +
-         mask_words(total_faces, N < 0 ? 0 : N, H, W) * 4 + raster_spill_bytes(total_faces, N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
+         mask_words(total_faces, N < 0 ? 0 : N, H, W) * 4 + full_thr_bytes(N, H, W) + raster_spill_bytes(total_faces, N < 0 ? 0 : N, H, W, K < 1 ? 1 : K);
 }
 
 int ur_project_faces(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
