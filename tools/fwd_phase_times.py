@@ -63,14 +63,14 @@ show("start", us(w[:, 0] - t0))
 show("scan + fine step", us(w[:, 1] - w[:, 0]))
 show("  face scan rounds", cu(w[:, 4]))
 show("  pair batches", cu(w[:, 5]))
-show("  lane = pixel route", cu(w[:, 6]))
+show("  full-list insertions", cu(w[:, 6]))
 show("  in-loop compaction", cu(w[:, 7]))
 show("  chunk-end barrier", cu(w[:, 8]))
 show("tail: sort", us(w[:, 2] - w[:, 1]))
 show("tail: shade + blend", us(w[:, 3] - w[:, 2]))
 show("whole wave", us(w[:, 3] - w[:, 0]))
 show("end time", us(w[:, 3] - t0))
-print("pairs %.0f in %.0f batches (fill %.2f), faces with pairs %.0f ; us per batch %.2f ; lane = pixel faces %.0f at %.2f us ; "
+print("pairs %.0f in %.0f batches (fill %.2f), faces with pairs %.0f ; us per batch %.2f ; full-list insertions %.0f at %.2f us ; "
       "compactions %.0f at %.2f us ; items %.0f" % (
           float(w[:, 10].sum()), float(w[:, 11].sum()), float(w[:, 10].sum() / (64 * w[:, 11].sum())), float(w[:, 13].sum()),
           float(cu(w[:, 5]).sum() / w[:, 11].sum()), float(w[:, 9].sum()), float(cu(w[:, 6]).sum() / max(1.0, float(w[:, 9].sum()))),
@@ -78,7 +78,7 @@ print("pairs %.0f in %.0f batches (fill %.2f), faces with pairs %.0f ; us per ba
 dur = us(w[:, 3] - w[:, 0])
 idx = torch.nonzero(live)[:, 0]
 for i in torch.argsort(us(w[:, 3] - t0), descending=True)[:8].tolist():
-    print("  late wave: wg %5d wave %d start %7.1f end %7.1f ; scan %.1f pairs %.1f (%d batches) lane=pixel %.1f (%d faces) "
+    print("  late wave: wg %5d wave %d start %7.1f end %7.1f ; scan %.1f pairs %.1f (%d batches) full-list %.1f (%d hits) "
           "compaction %.1f barrier %.1f sort %.1f shade %.1f ; items %d" % (
               int(idx[i]) // 4, int(idx[i]) % 4, float(us(w[i, 0] - t0)), float(us(w[i, 3] - t0)), float(cu(w[i, 4])),
               float(cu(w[i, 5])), int(w[i, 11]), float(cu(w[i, 6])), int(w[i, 9]), float(cu(w[i, 7])), float(cu(w[i, 8])),

@@ -695,9 +695,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   unsigned long long* s_hide = s_hide_all + wave * 64;
   unsigned long long* const lds_keys = s_keys_all + (size_t)wave * P.cap * 64;
   unsigned long long* const spill_keys = P.spill + (tile_live ? tile_id : 0) * (int64_t)(KL - P.cap) * 64;
-  unsigned long long last_hk = ~0ull;  // hide key this lane's list was last compacted against
-  bool any_stale = false;              // wave-uniform: some pixel's hide key moved since the last compaction
-  int compact_at = 0;                  // wave-uniform: longest list at which the next in-loop compaction is due (0: the LDS cap)
   float pxc[8], pyc[8];                // the tile's 8 column / 8 row centres (wave-uniform)
   unsigned livecols = 0, liverows = 0;
   // a full list's largest key (all ones while the list is not full): candidates that do not beat it are dropped
@@ -1001,35 +998,12 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
             // compacted view: lane r holds the r-th face that has pairs
             const int cpre = s_fpre[lane], cend = s_fpre[lane + 1];
             const unsigned cinfo = s_finfo[lane];
-            const int lim = min(P.cap, KL);
-            int r0 = 0;
-            while (r0 < nfp) {
-              // how many faces can go the pair way: each adds at most one entry to any pixel's list, and no list
-              // may pass its capacity KL (there the exact keep-the-KL-smallest rule takes over, lane = pixel)
-              int c2 = s_cnt[lane];
-              int cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
-              // Compaction is due when the longest list would leave LDS, or run out of room below K, with the faces at
-              // hand.  Where the lists stay beyond the LDS cap even after a compaction (dense meshes: deep lists),
-              // repeating it at every batch costs more than the batch; the next one then waits until the longest
-              // list has doubled (the tail compacts every list once more anyway).
-              const int due = compact_at > lim ? compact_at : lim;
-              if (any_stale && (cmax + (nfp - r0) > due || cmax + min(nfp - r0, 4) > KL)) {
-                // compact the lists whose hide key moved: drop what the nearest hiding hit made irrelevant
-                const unsigned long long hk = s_hide[lane];
-                const bool need = (hk != last_hk) && c2 > 0;
-                const int mx = __builtin_amdgcn_readfirstlane(wave_max(need ? c2 : 0));
-                const int j = keys.compact(need, c2, mx, hk);
-                full_known = 0;
-                if (need) {
-                  if (j < c2 && c2 >= KL) thr_keys[lane] = ~0ull;  // no longer full: the old largest key says nothing
-                  c2 = j;
-                  s_cnt[lane] = c2;
-                }
-                last_hk = hk;
-                any_stale = false;
-                cmax = __builtin_amdgcn_readfirstlane(wave_max(c2));
-                compact_at = cmax < lim ? 0 : min(KL, 2 * cmax);
-              }
+            {
+              const int r0 = 0;
+              // Lists are not compacted while faces are collected: entries that a later, nearer hiding hit made
+              // irrelevant are dropped in the tail's sorting passes, and a full list sheds them by itself (they are its
+              // largest keys, so the newcomers that matter replace them one by one).  In-loop compactions cost the
+              // dense-mesh workloads more than the shorter lists saved (5120-face meshes: +2.4 % without them).
               // Every face goes the pair way.  A hit on a FULL list (KL entries) is kept in its lane's registers
               // until the batch is through; the wave then takes those hits one by one, all 64 lanes scanning the
               // pixel's list together for its two largest entries: the newcomer replaces the largest if it beats it
@@ -1037,7 +1011,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
               // remembered, so that later candidates that cannot improve the list cost nothing.
               const int r1 = nfp;
               const int pbeg = __builtin_amdgcn_readlane(cpre, r0), pend = __builtin_amdgcn_readlane(cend, r1 - 1);
-              bool improved = false;
               for (int pb = pbeg; pb < pend; pb += 64) {
                 const int pidx = pb + lane;
                 const bool act = pidx < pend;
@@ -1071,7 +1044,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                     const bool hides = hides_rest(ev.sd, P.sigma, P.mode);
                     const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
                                                    ((unsigned)(fbase + s_bin[c * kSub + src]) << 1) | (hides ? 1u : 0u);
-                    if (hides && key < hk) { atomicMin(&s_hide[pl], key); hk = key; improved = true; }
+                    if (hides && key < hk) { atomicMin(&s_hide[pl], key); hk = key; }
                     if (key <= hk) {
                       const int slot = atomicAdd(&s_cnt[pl], 1);
                       if (slot < KL) {
@@ -1089,8 +1062,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 const unsigned long long pending = __ballot(over_key != ~0ull);
                 if (pending) full_list_insert(pending, over_key, pl, lds_keys, spill_keys, thr_keys, P.cap, KL);
               }
-              any_stale = any_stale || __any(improved);
-              r0 = r1;
             }
           }
         }
