@@ -1414,20 +1414,22 @@ size_t wave_groups(int H, int W) { return (size_t)((H + 15) / 16) * ((W + 15) / 
 constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4 + 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 8 +
                                    2 * kSub * 16 + 2 * kSub * 5 * 16;
 
-// K-list slots per pixel kept in LDS (the rest spills to global memory).  Four workgroups per CU (40 KB each) is the
-// best trade for the headline meshes, whose per-pixel lists are short; where many small faces fall inside every
-// pixel's blur disc the lists run deep and LDS residency pays more than occupancy (measured: 5120 faces at 128^2
-// +9 % with three workgroups per CU, 20480 faces at 256^2 / K=100 +12 % with two), so the budget follows the mesh's
-// face density on the image: faces per pixel >= 0.2 -> three workgroups per CU, and two when K > 64 as well.
-// the fused backward's table shapes follow the same density threshold (see k_render_bwd)
+// K-list slots per pixel kept in LDS (the rest spills to global memory): what fits four workgroups per CU (40 KB
+// each).  Round 1 traded occupancy for LDS residency on dense meshes (three / two workgroups per CU), because lists
+// leaving LDS made the in-loop compactions and the lane = pixel full-list route dear; with both gone (appends beyond
+// the cap are fire-and-forget stores) occupancy wins everywhere: 5120-face meshes 286 -> 250 us, 20480 faces at
+// 256^2 / K=100 1.15 -> 0.85 ms.
+// the fused backward's table shapes are picked by the mesh's face density on the image (see k_render_bwd)
 bool render_bwd_dense(int64_t total_faces, int N, int H, int W) {
   return (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W) >= 0.2;
 }
 
-int raster_cap(int64_t total_faces, int N, int H, int W, int K) {
+// The fragment-writing build (lane = pixel, keep-the-K-smallest in place) still prefers its lists in LDS on dense
+// meshes: three workgroups per CU from 0.2 faces per pixel, two when K > 64 as well.
+int raster_cap(int64_t total_faces, int N, int H, int W, int K, bool fused = true) {
   const int KL = list_cap(K);
   const double density = (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W);
-  const size_t budget = density < 0.2 ? (size_t)kLdsBudget : (K > 64 ? (size_t)80 * 1024 : (size_t)52 * 1024);
+  const size_t budget = (fused || density < 0.2) ? (size_t)kLdsBudget : (K > 64 ? (size_t)80 * 1024 : (size_t)52 * 1024);
   const int fit = (int)((budget - kRasterFixedLds) / (4 * 64 * 8));
   return KL < fit ? KL : fit;
 }
@@ -1444,7 +1446,7 @@ template <int MODE, bool BIGK, bool MASKS> int launch_raster_k(RasterParams P, h
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
   P.KL = list_cap(P.K);
-  P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K);
+  P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K, MODE == 2);
   const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static LdsSlot lds_slot;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE, BIGK, MASKS>), lds, lds_slot)) return rc;
