@@ -1094,11 +1094,13 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     hide_key = s_hide[lane];
     int n_rel = cnt;
     constexpr int kDeep = 8;
-    // Every list drops its hidden entries (behind the hide key) on the way through its sort below: they are replaced
-    // by the all-ones pad, which sorts to the end.  Only lists too long for a sorting network (more than 128 entries:
-    // K > 128) are compacted in place first.
-    if (BIGK && __any(hide_key != ~0ull && cnt > 128)) {
-      const bool need = hide_key != ~0ull && cnt > 128;
+    // Lists too long for the register network (more than kDeep entries) first drop, in place, what their pixel's nearest
+    // hiding hit made irrelevant (nothing was dropped while faces were collected): many of them then fit the register
+    // network after all, and the cross-lane sorts get shorter (5120-face meshes +3 %, 20480 faces / K=100 +3 %).  Short
+    // lists drop their hidden entries on the way through the network: they are replaced by the all-ones pad, which
+    // sorts to the end.
+    if (__any(hide_key != ~0ull && cnt > kDeep)) {
+      const bool need = hide_key != ~0ull && cnt > kDeep;
       const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(need ? cnt : 0));
       const int j = keys.compact(need, cnt, maxcnt, hide_key);
       if (need) n_rel = j;
