@@ -167,6 +167,46 @@ __device__ __forceinline__ float wave_fmax(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(r, 63));
 }
 
+// Value of lane (lane ^ D), D a power of two: the exchange step of the cross-lane sorting networks.  Distances up to 8
+// stay inside a 16-lane row and are one or two data-parallel-primitive moves on the VALU (quad permutes for 1 and 2,
+// two bank-masked row shifts for 4, a row rotation by 8 -- 16 lanes rotated by 8 IS the xor); 16 and 32 are gfx950's
+// row-pair swaps followed by a select.  A __shfl_xor is a round trip through the LDS crossbar per 32 bits instead, and
+// a bitonic network is a chain of them: the sorts of a silhouette bin's long lists spent their time waiting on those.
+template <int D> __device__ __forceinline__ unsigned lane_xor(unsigned v) {
+  static_assert(D == 1 || D == 2 || D == 4 || D == 8 || D == 16 || D == 32, "lane_xor: D");
+  if constexpr (D == 1) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+  } else if constexpr (D == 2) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+  } else if constexpr (D == 4) {
+    int r = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0x5, false);  // row_shl:4 -> lanes 0-3, 8-11 of a row
+    r = __builtin_amdgcn_update_dpp(r, (int)v, 0x114, 0xf, 0xa, false);      // row_shr:4 -> lanes 4-7, 12-15
+    return (unsigned)r;
+  } else if constexpr (D == 8) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  } else if constexpr (D == 16) {
+    const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // p[0]: rows 0,0,2,2 ; p[1]: rows 1,1,3,3
+    return (__lane_id() & 16) ? p[0] : p[1];
+  } else {
+    const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // p[0]: lower half twice ; p[1]: upper half twice
+    return (__lane_id() & 32) ? p[0] : p[1];
+  }
+}
+template <int D> __device__ __forceinline__ unsigned long long lane_xor(unsigned long long v) {
+  return ((unsigned long long)lane_xor<D>((unsigned)(v >> 32)) << 32) | lane_xor<D>((unsigned)v);
+}
+// the same with the distance as a value a fully unrolled loop has made constant
+__device__ __forceinline__ unsigned long long lane_xor_d(unsigned long long v, int d) {
+  switch (d) {
+    case 1: return lane_xor<1>(v);
+    case 2: return lane_xor<2>(v);
+    case 4: return lane_xor<4>(v);
+    case 8: return lane_xor<8>(v);
+    case 16: return lane_xor<16>(v);
+    default: return lane_xor<32>(v);
+  }
+}
+
 constexpr int kPrepBins = 4096;  // bins per image the face-prep kernel counts in LDS (16 KB); beyond: global atomics
 // Face masks (k_project_prep_mesh -> k_raster<2, ., true>): per (mesh, bin, part) 256 bits, bit j = face part * 256 + j
 // of the mesh passes the bin's box test.  Up to kMaskBins bins per image, at most kMaskAxis of them along either axis.
@@ -1190,7 +1230,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           for (int k = 2; k <= Wd; k <<= 1)
 #pragma unroll
             for (int d = k >> 1; d > 0; d >>= 1) {
-              const unsigned long long o = __shfl_xor(v, d, 64);
+              const unsigned long long o = lane_xor_d(v, d);
               const bool take_min = ((j & d) == 0) == ((j & k) == 0);
               v = (take_min == (o < v)) ? o : v;
             }
@@ -1239,7 +1279,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 #pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2) {
                   const int e = lane + 64 * r2;
-                  const unsigned long long o = __shfl_xor(v[r2], d, 64);
+                  const unsigned long long o = lane_xor_d(v[r2], d);
                   const bool take_min = ((e & d) == 0) == ((e & k) == 0);
                   v[r2] = (take_min == (o < v[r2])) ? o : v[r2];
                 }
