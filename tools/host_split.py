@@ -48,3 +48,33 @@ for _ in range(n):
     o = Nop.apply(verts, maps, R, T); o.backward(o.detach())
 t1 = time.perf_counter()
 print("empty Function fwd+bwd round trip: %.1f us" % ((t1 - t0) / n * 1e6))
+# the native wrappers alone (allocations + argument marshalling + the C call), then the bare C call cost by difference
+import math
+s = 1.0 / math.tan(math.radians(15.0))
+F = sc["faces"].shape[0]
+first = torch.arange(B, device=dev, dtype=torch.int64) * F
+num = torch.full((B,), F, device=dev, dtype=torch.int64)
+sigma = 1e-4
+blur = math.log(1.0 / 1e-4 - 1.0) * sigma
+fuv = sc["verts_uvs"][sc["faces"]].contiguous()
+vd, md, Rd, Td = verts.detach(), maps.detach(), R.detach(), T.detach()
+def nf():
+    return native.render_meshes_forward(vd, sc["faces"], Rd, Td, s, s, first, num, (H, H), blur, K, True, md, fuv, True,
+                                        sigma, (1.0, 1.0, 1.0), None, 1, True, True)
+def nb(st, gm):
+    return native.render_meshes_backward(cot, vd, sc["faces"], Rd, Td, s, s, first, num, (H, H), blur, K, True, md, fuv,
+                                         True, sigma, (1.0, 1.0, 1.0), None, 1, st, gm, True, True, True, True, True)
+for _ in range(20):
+    img, st, gm = nf(); nb(st, gm)
+torch.cuda.synchronize()
+tf = tb = 0.0
+for _ in range(n):
+    t0 = time.perf_counter(); img, st, gm = nf(); t1 = time.perf_counter(); nb(st, gm); t2 = time.perf_counter()
+    tf += t1 - t0; tb += t2 - t1
+torch.cuda.synchronize()
+print("native wrappers alone: forward %.1f us, backward %.1f us" % (tf / n * 1e6, tb / n * 1e6))
+t0 = time.perf_counter()
+for _ in range(n):
+    a = torch.empty(B, 4, H, H, dtype=torch.float32, device=dev)
+t1 = time.perf_counter()
+print("one torch.empty: %.2f us" % ((t1 - t0) / n * 1e6))

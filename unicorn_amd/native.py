@@ -415,75 +415,97 @@ def _rgb_ptr(v):
     return None if v is None else ctypes.addressof(_rgb(v))
 
 
+_step_layouts = {}
+
+
+def _step_layout(N, F, H, W, K):
+    """byte offsets inside the one allocation a render step keeps between its two calls:
+    [face_verts | layers | workspace | backward scratch | face-gradient accumulator], each part 256-byte aligned
+    -> (layers, workspace, workspace bytes, scratch, scratch bytes, accumulator, total)"""
+    key = (N, F, H, W, K)
+    v = _step_layouts.get(key)
+    if v is None:
+        al = lambda x: (x + 255) // 256 * 256
+        NF = N * F
+        o_lay = al(NF * 36)
+        o_ws = o_lay + al(_sized("ur_layers_elems", N, H, W, K) * 4)
+        ws_b = workspace_bytes(NF, N, H, W, K)
+        o_scr = o_ws + al(ws_b)
+        scr_b = _sized("ur_backward_scratch_bytes", N, H, W, K)
+        o_acc = o_scr + al(scr_b)
+        v = _step_layouts[key] = (o_lay, o_ws, ws_b, o_scr, scr_b, o_acc, o_acc + al(NF * 36))
+    return v
+
+
+def step_face_verts(state, N, F):
+    """the projected corners (N*F,3,3) ur_render_meshes_forward left in a step's allocation"""
+    return state[:N * F * 36].view(torch.float32).view(N * F, 3, 3)
+
+
 def render_meshes_forward(verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_faces, image_size, blur_radius,
                           faces_per_pixel, clip_barycentric_coords, maps, face_uvs, face_uvs_shared, sigma, background,
                           ambient, mode, need_geometry_grads=False, need_map_grads=False, cull_backfaces=False):
-    """equal-sized meshes: camera + rasterizer + shader in one call.  -> image (N,4,H,W), face_verts (N*F,3,3),
-    layers, workspace, grads (one zero-filled float buffer holding the backward's two accumulators, or None)"""
+    """equal-sized meshes: camera + rasterizer + shader in one call.  -> image (N,4,H,W), state, grad_maps.
+    `state`: ONE uint8 allocation holding everything the step keeps for its backward (_step_layout: projected corners,
+    layers, workspace, the backward's scratch and its face-gradient accumulator) -- the host side of a step is a few
+    allocator calls and two C calls, so each allocation saved shows in the eager rate.  `grad_maps`: the texture
+    gradient's buffer, cleared on the way (None unless need_map_grads); the accumulator is cleared likewise when
+    need_geometry_grads."""
     N, V = verts.shape[:2]
     F, fstride = _faces_layout(faces, N)
     H, W = image_size
     K = int(faces_per_pixel)
     Ht, Wt = maps.shape[1:3]
     dev = verts.device
-    NF = N * F
-    face_verts = torch.empty(NF, 3, 3, dtype=torch.float32, device=dev)
+    o_lay, o_ws, ws_b, _, _, o_acc, total = _step_layout(N, F, H, W, K)
     image = torch.empty(N, 4, H, W, dtype=torch.float32, device=dev)
-    layers = torch.empty(_sized("ur_layers_elems", N, H, W, K), dtype=torch.int32, device=dev)
-    ws = _workspace(NF, dev, N, H, W, K)
-    grads = gfv = gmaps = None
-    if need_geometry_grads or need_map_grads:
-        n_fv = NF * 9 if need_geometry_grads else 0
-        grads = torch.empty(n_fv + (maps.numel() if need_map_grads else 0), dtype=torch.float32, device=dev)
-        gfv = grads if need_geometry_grads else None
-        gmaps = grads[n_fv:] if need_map_grads else None
+    state = torch.empty(total, dtype=torch.uint8, device=dev)
+    gmaps = torch.empty_like(maps) if need_map_grads else None
+    base = state.data_ptr()
     with _on(verts), _timed("ur_render_meshes_forward", verts):
         _check(lib().ur_render_meshes_forward(
             _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride, _ptr(R, torch.float32),
             _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(mesh_first_face, torch.int64),
             _ptr(mesh_num_faces, torch.int64), H, W, float(blur_radius), K, int(clip_barycentric_coords),
             int(cull_backfaces), _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt,
-            float(sigma), _rgb_ptr(background), _rgb_ptr(ambient), int(mode), _ptr(face_verts), _ptr(image),
-            _ptr(layers), _ptr(gfv, None, True), _ptr(gmaps, None, True), _ptr(ws), ws.numel(), _stream(verts)),
-            "ur_render_meshes_forward")
-    return image, face_verts, layers, ws, grads
+            float(sigma), _rgb_ptr(background), _rgb_ptr(ambient), int(mode), base, image.data_ptr(), base + o_lay,
+            base + o_acc if need_geometry_grads else None, None if gmaps is None else gmaps.data_ptr(), base + o_ws,
+            ws_b, _stream(verts)), "ur_render_meshes_forward")
+    return image, state, gmaps
 
 
 def render_meshes_backward(grad_image, verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_faces, image_size,
                            blur_radius, faces_per_pixel, clip_barycentric_coords, maps, face_uvs, face_uvs_shared, sigma,
-                           background, ambient, mode, layers, workspace, grads, need_verts, need_R, need_T, need_maps):
-    """-> grad_verts, grad_R, grad_T, grad_maps (None where not needed).  `grads`: the zero-filled buffer the forward
-    prepared for exactly these needs, or None (then one is cleared here)."""
+                           background, ambient, mode, state, grad_maps, grads_are_zero, need_verts, need_R, need_T,
+                           need_maps):
+    """-> grad_verts, grad_R, grad_T, grad_maps (None where not needed).  `state` / `grad_maps`: what the forward
+    returned; grads_are_zero: they still are as the forward left them (False on a second backward through the same
+    step: the call then clears the accumulators itself, and grad_maps may be None = allocate one)."""
     N, V = verts.shape[:2]
     F, fstride = _faces_layout(faces, N)
     H, W = image_size
     K = int(faces_per_pixel)
     Ht, Wt = maps.shape[1:3]
-    dev = verts.device
-    NF = N * F
+    o_lay, o_ws, ws_b, o_scr, scr_b, o_acc, total = _step_layout(N, F, H, W, K)
+    assert state.numel() == total
     geometry = need_verts or need_R or need_T
-    n_fv = NF * 9 if geometry else 0
-    zero = grads is not None
-    if grads is None:
-        grads = torch.empty(n_fv + (maps.numel() if need_maps else 0), dtype=torch.float32, device=dev)
-    assert grads.numel() == n_fv + (maps.numel() if need_maps else 0)
-    gfv = grads if geometry else None
-    gmaps = grads[n_fv:].view(maps.shape) if need_maps else None
+    if need_maps and grad_maps is None:
+        grad_maps, grads_are_zero = torch.empty_like(maps), False
     gv = torch.empty_like(verts) if need_verts else None
     gR = torch.empty_like(R) if need_R else None
     gT = torch.empty_like(T) if need_T else None
-    scratch = torch.empty(_sized("ur_backward_scratch_bytes", N, H, W, K), dtype=torch.uint8, device=dev)
+    base = state.data_ptr()
     with _on(verts), _timed("ur_render_meshes_backward", verts):
         _check(lib().ur_render_meshes_backward(
             _ptr(grad_image, torch.float32), _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
             _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(mesh_first_face, torch.int64),
             _ptr(mesh_num_faces, torch.int64), H, W, float(blur_radius), K, int(clip_barycentric_coords),
             _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt, float(sigma),
-            _rgb_ptr(background), _rgb_ptr(ambient), int(mode), _ptr(layers, torch.int32), _ptr(workspace),
-            workspace.numel(), _ptr(scratch), scratch.numel(), _ptr(gfv, None, True), _ptr(gmaps, None, True),
-            int(zero), _ptr(gv, None, True), _ptr(gR, None, True), _ptr(gT, None, True), _stream(verts)),
-            "ur_render_meshes_backward")
-    return gv, gR, gT, gmaps
+            _rgb_ptr(background), _rgb_ptr(ambient), int(mode), base + o_lay, base + o_ws, ws_b, base + o_scr, scr_b,
+            base + o_acc if geometry else None, grad_maps.data_ptr() if need_maps else None, int(bool(grads_are_zero)),
+            None if gv is None else gv.data_ptr(), None if gR is None else gR.data_ptr(),
+            None if gT is None else gT.data_ptr(), _stream(verts)), "ur_render_meshes_backward")
+    return gv, gR, gT, (grad_maps if need_maps else None)
 
 
 def mesh_regularizers(verts, edge_quads, nbr_offsets, nbr_index, need_grad=True):

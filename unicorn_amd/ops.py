@@ -135,39 +135,43 @@ def render_layered(face_verts, maps, first, nfaces, image_size, blur_radius, K, 
 class _RenderMeshes(Function):
     """ur_render_meshes_forward / _backward: camera + rasterizer + shader of a batch of equal-sized meshes in one call
     each way (MeshRenderer.forward, renderer.py:48-49).  The forward also clears the backward's gradient accumulators
-    (no fill launch in the backward) when it knows which gradients will be wanted."""
+    (no fill launch in the backward) when it knows which gradients will be wanted.  Everything that is not a tensor
+    travels as ONE tuple: autograd's per-argument bookkeeping is a visible share of an eager step's host time."""
 
     @staticmethod
-    def forward(ctx, verts, maps, R, T, faces, sx, sy, first, nfaces, image_size, blur_radius, K, clip, face_uvs,
-                shared, sigma, background, ambient, mode):
+    def forward(ctx, verts, maps, R, T, faces, first, nfaces, face_uvs, cfg):
         verts, maps, R, T = verts.contiguous(), maps.contiguous(), R.contiguous(), T.contiguous()
+        sx, sy, image_size, blur_radius, K, clip, shared, sigma, background, ambient, mode = cfg
         need_v, need_m, need_R, need_T = ctx.needs_input_grad[:4]
-        image, _, layers, ws, grads = native.render_meshes_forward(
+        image, state, gmaps = native.render_meshes_forward(
             verts, faces, R, T, sx, sy, first, nfaces, image_size, blur_radius, K, clip, maps, face_uvs, shared, sigma,
             background, ambient, mode, need_geometry_grads=need_v or need_R or need_T, need_map_grads=need_m)
-        ctx.save_for_backward(verts, maps, R, T, faces, first, nfaces, face_uvs, layers, ws)
-        ctx.grads = grads
-        ctx.cfg = (sx, sy, image_size, blur_radius, K, clip, shared, sigma, background, ambient, mode)
+        ctx.save_for_backward(verts, maps, R, T, faces, first, nfaces, face_uvs)
+        # the step's own buffers (never seen by the caller, so no version counting needed): plain attributes
+        ctx.step = (state, gmaps, True)
+        ctx.cfg = cfg
         return image
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_image):
-        verts, maps, R, T, faces, first, nfaces, face_uvs, layers, ws = ctx.saved_tensors
+        verts, maps, R, T, faces, first, nfaces, face_uvs = ctx.saved_tensors
         sx, sy, image_size, blur_radius, K, clip, shared, sigma, background, ambient, mode = ctx.cfg
         need_v, need_m, need_R, need_T = ctx.needs_input_grad[:4]
-        grads, ctx.grads = ctx.grads, None  # cleared by the forward; a second backward (retain_graph) clears its own
+        state, gmaps, fresh = ctx.step
+        ctx.step = (state, None, False)  # a second backward (retain_graph) clears its own accumulators
         gv, gR, gT, gmaps = native.render_meshes_backward(
             grad_image.contiguous(), verts, faces, R, T, sx, sy, first, nfaces, image_size, blur_radius, K, clip, maps,
-            face_uvs, shared, sigma, background, ambient, mode, layers, ws, grads, need_v, need_R, need_T, need_m)
-        return (gv, gmaps, gR, gT) + (None,) * 15
+            face_uvs, shared, sigma, background, ambient, mode, state, gmaps, fresh, need_v, need_R, need_T, need_m)
+        return gv, gmaps, gR, gT, None, None, None, None, None
 
 
 def render_meshes(verts, maps, R, T, faces, sx, sy, first, nfaces, image_size, blur_radius, K, clip, face_uvs, shared,
                   sigma, background, ambient, mode):
-    return _RenderMeshes.apply(verts, maps, R, T, faces, float(sx), float(sy), first, nfaces, tuple(image_size),
-                               float(blur_radius), int(K), bool(clip), face_uvs, bool(shared), float(sigma),
-                               tuple(background), None if ambient is None else tuple(ambient), int(mode))
+    return _RenderMeshes.apply(verts, maps, R, T, faces, first, nfaces, face_uvs,
+                               (float(sx), float(sy), tuple(image_size), float(blur_radius), int(K), bool(clip),
+                                bool(shared), float(sigma), tuple(background),
+                                None if ambient is None else tuple(ambient), int(mode)))
 
 
 def project_faces(verts, faces, R, T, sx, sy):

@@ -78,15 +78,31 @@ class PointLights(AmbientLights):
         self.diffuse_color, self.specular_color, self.location = diffuse_color, specular_color, location
 
 
+_rgb3_seen = {}
+
+
 def _rgb3(c):
     """colour given as tuple / nested list / tensor -> 3 python floats, without touching the GPU stream unless the
     caller stored a device tensor"""
+    if type(c) is tuple:  # immutable and hashable (unless it holds tensors / lists): remembered
+        try:
+            hit = _rgb3_seen.get(c)
+        except TypeError:
+            hit = None
+        if hit is not None:
+            return hit
     if not torch.is_tensor(c):  # plain numbers (the configs' case): no tensor round trip
         flat = c
         while isinstance(flat, (tuple, list)) and len(flat) == 1:
             flat = flat[0]
         if isinstance(flat, (tuple, list)) and len(flat) == 3 and all(isinstance(v, (int, float)) for v in flat):
-            return (float(flat[0]), float(flat[1]), float(flat[2]))
+            out = (float(flat[0]), float(flat[1]), float(flat[2]))
+            if type(c) is tuple and len(_rgb3_seen) < 64:
+                try:
+                    _rgb3_seen[c] = out
+                except TypeError:
+                    pass
+            return out
     t = torch.as_tensor(c, dtype=torch.float32).detach().cpu().flatten()
     assert t.numel() == 3, "colour must have 3 components"
     return tuple(float(v) for v in t)
@@ -107,7 +123,7 @@ class MeshRasterizer(nn.Module):
         return self
 
     def _mesh_index(self, N, F, device):
-        key = (N, F, str(device))
+        key = (N, F, device)
         if key not in self._idx_cache:
             first = torch.arange(N, dtype=torch.int64, device=device) * F
             self._idx_cache[key] = (first, torch.full((N,), F, dtype=torch.int64, device=device))

@@ -63,8 +63,7 @@ class TexturesUV:
             vu, fu = self._verts_uvs, self._faces_uvs
             if vu.requires_grad:
                 return vu[0][fu[0]].contiguous(), True
-            key = (vu.data_ptr(), vu._version, tuple(vu.shape[1:]), fu.data_ptr(), fu._version, tuple(fu.shape[1:]),
-                   str(vu.device))
+            key = (vu.data_ptr(), vu._version, vu.shape, fu.data_ptr(), fu._version, fu.shape, vu.device)
             hit = TexturesUV._uv_cache.get(key)
             if hit is None:
                 if len(TexturesUV._uv_cache) > 16:
