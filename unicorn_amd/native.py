@@ -114,13 +114,13 @@ def _ptr(t, dtype=None, allow_none=False):
         if allow_none:
             return None
         raise ValueError("missing tensor")
+    if t.is_cuda and t.is_contiguous() and (dtype is None or t.dtype is dtype):  # the usual case, one test
+        return t.data_ptr()
     if not t.is_cuda:
         raise ValueError("unicorn_amd kernels need tensors on the GPU (got a CPU tensor); there is no CPU path")
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
-    if dtype is not None and t.dtype != dtype:
-        raise ValueError(f"expected {dtype}, got {t.dtype}")
-    return t.data_ptr()
+    raise ValueError(f"expected {dtype}, got {t.dtype}")
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -148,6 +148,22 @@ class _on:
     def __exit__(self, *a):
         if self._ctx is not None:
             self._ctx.__exit__(*a)
+
+
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _call(name, t, *args):
+    """one C-ABI call on t's GPU.  The usual case -- t's GPU is current, no timing asked for -- goes straight to the
+    library; otherwise through the device switch / the event pair."""
+    fn = getattr(lib(), name)
+    if _timing is None and _cur_device is not None and t.is_cuda and t.device.index == _cur_device():
+        rc = fn(*args)
+    else:
+        with _on(t), _timed(name, t):
+            rc = fn(*args)
+    if rc != 0:
+        _check(rc, name)
 
 
 _size_cache = {}
@@ -462,15 +478,14 @@ def render_meshes_forward(verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_
     state = torch.empty(total, dtype=torch.uint8, device=dev)
     gmaps = torch.empty_like(maps) if need_map_grads else None
     base = state.data_ptr()
-    with _on(verts), _timed("ur_render_meshes_forward", verts):
-        _check(lib().ur_render_meshes_forward(
+    _call("ur_render_meshes_forward", verts,
             _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride, _ptr(R, torch.float32),
             _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(mesh_first_face, torch.int64),
             _ptr(mesh_num_faces, torch.int64), H, W, float(blur_radius), K, int(clip_barycentric_coords),
             int(cull_backfaces), _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt,
             float(sigma), _rgb_ptr(background), _rgb_ptr(ambient), int(mode), base, image.data_ptr(), base + o_lay,
             base + o_acc if need_geometry_grads else None, None if gmaps is None else gmaps.data_ptr(), base + o_ws,
-            ws_b, _stream(verts)), "ur_render_meshes_forward")
+            ws_b, _stream(verts))
     return image, state, gmaps
 
 
@@ -495,8 +510,7 @@ def render_meshes_backward(grad_image, verts, faces, R, T, sx, sy, mesh_first_fa
     gR = torch.empty_like(R) if need_R else None
     gT = torch.empty_like(T) if need_T else None
     base = state.data_ptr()
-    with _on(verts), _timed("ur_render_meshes_backward", verts):
-        _check(lib().ur_render_meshes_backward(
+    _call("ur_render_meshes_backward", verts,
             _ptr(grad_image, torch.float32), _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
             _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(mesh_first_face, torch.int64),
             _ptr(mesh_num_faces, torch.int64), H, W, float(blur_radius), K, int(clip_barycentric_coords),
@@ -504,7 +518,7 @@ def render_meshes_backward(grad_image, verts, faces, R, T, sx, sy, mesh_first_fa
             _rgb_ptr(background), _rgb_ptr(ambient), int(mode), base + o_lay, base + o_ws, ws_b, base + o_scr, scr_b,
             base + o_acc if geometry else None, grad_maps.data_ptr() if need_maps else None, int(bool(grads_are_zero)),
             None if gv is None else gv.data_ptr(), None if gR is None else gR.data_ptr(),
-            None if gT is None else gT.data_ptr(), _stream(verts)), "ur_render_meshes_backward")
+            None if gT is None else gT.data_ptr(), _stream(verts))
     return gv, gR, gT, (grad_maps if need_maps else None)
 
 
