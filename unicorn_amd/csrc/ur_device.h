@@ -97,7 +97,8 @@ __device__ __forceinline__ bool eval_face(const Face& f, float px, float py, flo
   if (clip) {
     c0 = max_s(c0, 0.0f); c1 = max_s(c1, 0.0f); c2 = max_s(c2, 0.0f);
     const float s = max_s(c0 + c1 + c2, 1e-5f);
-    c0 = c0 / s; c1 = c1 / s; c2 = c2 / s;
+    const float ys = 1.0f / s;  // one IEEE division, then three exact quotients (div_by): same bits as c / s
+    c0 = div_by(c0, s, ys); c1 = div_by(c1, s, ys); c2 = div_by(c2, s, ys);
   }
   float pz = c0 * f.z0 + c1 * f.z1 + c2 * f.z2;
   if (pz < 0.0f) return false;
