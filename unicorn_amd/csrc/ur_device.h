@@ -11,10 +11,10 @@ constexpr float kEps = 1e-8f;
 constexpr int kTile = 8;  // a wavefront rasterizes one 8x8 pixel tile: lane = pixel
 
 // The hardware's minimum / maximum (one instruction; a compare + select is three issue slots with its hazard wait, and
-// the pair evaluation has a dozen of them).  They differ from std::min / std::max -- what the oracle uses -- only in
+// the pair evaluation has a dozen of them).  They differ from std::min / std::max -- what the CPU checker uses -- only in
 // which zero comes out of (-0, +0) and in dropping a NaN operand; no sign of a zero reaches a result here (no
 // division by, square root or copysign of these values: a clamped -0 multiplies, adds and compares like +0), so every
-// output still compares equal to the oracle's, value for value.
+// output still compares equal to the checker's, value for value.
 __device__ __forceinline__ float min_s(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float max_s(float a, float b) { return __builtin_fmaxf(a, b); }
 

@@ -129,6 +129,18 @@ int ensure_dynamic_lds(const void* kernel, size_t bytes, LdsSlot& slot) {
   return UR_OK;
 }
 
+// Lanes of one wave hand values to each other through LDS (one lane writes a slot, another reads it) without a
+// barrier: the hardware executes a wave's LDS operations in order.  The COMPILER must be told as well -- to the C++
+// memory model an unsynchronised write by another lane is a data race it may ignore, and it does: it forwards a lane's
+// own earlier store to its later load of the same slot and drops the load (seen on a marks[] read, which then missed
+// the other lanes' marks).  A release + acquire fence at wavefront scope between the writes and the reads says so and
+// emits no instruction.
+__device__ __forceinline__ void wave_lds_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Wave-wide inclusive scans on the VALU's data-parallel-primitive lanes (row shifts inside a 16-lane row, then the
 // two row broadcasts): six VALU operations, where a __shfl_up ladder is six dependent trips through the LDS crossbar.
 // `ident` is the operation's neutral element (what a lane combines with when it has no source lane).
@@ -618,6 +630,7 @@ __device__ __attribute__((noinline)) void full_list_insert(unsigned long long pe
                                                            int cap, int KL) {
   const int lane = threadIdx.x & 63;
   while (pending) {
+    wave_lds_handoff();  // lane 0's replacement of the last round is part of the list the next round scans
     const int srcl = __builtin_ctzll(pending);
     pending &= pending - 1;
     const int opl = __builtin_amdgcn_readlane(over_pl, srcl);
@@ -726,6 +739,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   unsigned long long hide_key = ~0ull;  // smallest key among the hits that hide the rest
   bool stale = false;                   // hide_key moved since this lane's list was last compacted
   const bool can_cull = (MODE == 2) && (P.clip != 0 || P.blur == 0.0f);
+  // hides_rest() as two compares against wave-uniform bounds (the mode is a runtime value: testing it per pair costs
+  // a tree of scalar branches): hard blend d <= 0 ; clip-inside d < 0 ; sigmoid d < -20 sigma
+  const float hide_lt = P.mode == 2 ? -20.0f * P.sigma : (P.mode == 1 ? 0.0f : -__builtin_inff());
+  const float hide_le = P.mode == 0 ? 0.0f : -__builtin_inff();
 
   // MODE 2 evaluates (face, pixel) PAIRS dealt out over the lanes (see the fine step); the per-pixel list length and
   // hide key then live in LDS, where any lane can reach them with integer atomics.
@@ -1012,7 +1029,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           // become covered, so a stale snapshot errs on the safe side.)
           bool behind = false;
           if (can_cull) {
-            const unsigned long long hk0 = s_hide[lane];
+            const unsigned long long hk0 = __hip_atomic_load(&s_hide[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             const unsigned long long uncovered = __ballot(hk0 == ~0ull);
             const int zb = wave_max(hk0 == ~0ull ? 0 : (int)(hk0 >> 32));  // depths are >= +0: bits order like ints
             unsigned long long rows = (unsigned long long)rowm * 0x0101010101010101ull & 0x8040201008040201ull;
@@ -1027,6 +1044,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           if (nfp > 0) {
             const int incl = wave_scan_add(area);
             const int total_pairs = __builtin_amdgcn_readlane(incl, 63);
+            wave_lds_handoff();  // (the last chunk's batches have read these slots)
             if (area > 0) {
               const int rank = __popcll(m & ((1ull << lane) - 1ull));
               s_fpre[rank] = incl - area;
@@ -1035,6 +1053,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                               ((unsigned)rw << 12) | ((unsigned)((32768 + rw - 1) / rw) << 16);
             }
             if (lane + 1 >= nfp) s_fpre[lane + 1] = (lane + 1 == nfp) ? total_pairs : 0x7fffffff;
+            wave_lds_handoff();
             // compacted view: lane r holds the r-th face that has pairs
             const int cpre = s_fpre[lane], cend = s_fpre[lane + 1];
             const unsigned cinfo = s_finfo[lane];
@@ -1059,11 +1078,14 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 // pair's slot with their rank + 1, slot 0 takes the face that holds pair pb, and a running maximum
                 // spreads the marks to the right.
                 unsigned char* marks = reinterpret_cast<unsigned char*>(s_fpre + 68);
+                wave_lds_handoff();  // (the last batch has read its marks)
                 marks[lane] = 0;
                 const bool mine = lane >= r0 && lane < r1 && cend > pb && cpre < pb + 64;
                 const int rfirst = __builtin_ctzll(__ballot(mine));
                 if (mine && cpre > pb) marks[cpre - pb] = (unsigned char)(lane + 1);
-                const int rr = wave_scan_max(lane == 0 ? rfirst + 1 : (int)marks[lane]) - 1;
+                wave_lds_handoff();
+                const int mark = (int)marks[lane];  // read by every lane: a select below, not a branch around the load
+                const int rr = wave_scan_max(lane == 0 ? rfirst + 1 : mark) - 1;
                 const int mypre = s_fpre[rr];
                 const unsigned info = s_finfo[rr];
                 const int q = pidx - mypre;
@@ -1075,13 +1097,13 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 if (act) {
                   const Face fc = unpack_face(rcs[src * 5 + 0], rcs[src * 5 + 1], rcs[src * 5 + 2], rcs[src * 5 + 3],
                                               rcs[src * 5 + 4]);
-                  unsigned long long hk = s_hide[pl];
+                  unsigned long long hk = __hip_atomic_load(&s_hide[pl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                   bool hit = true;
                   if (can_cull && hk != ~0ull) hit = !(fc.zmin * 0.9999f > __uint_as_float((unsigned)(hk >> 32)));
                   Eval ev;
                   if (hit) hit = eval_face(fc, qx, qy, P.blur, P.clip != 0, ev);
                   if (hit) {
-                    const bool hides = hides_rest(ev.sd, P.sigma, P.mode);
+                    const bool hides = ev.sd < hide_lt || ev.sd <= hide_le;  // = hides_rest(ev.sd, P.sigma, P.mode)
                     const unsigned long long key = ((unsigned long long)__float_as_uint(ev.pz) << 32) |
                                                    ((unsigned)(fbase + s_bin[c * kSub + src]) << 1) | (hides ? 1u : 0u);
                     if (hides && key < hk) { atomicMin(&s_hide[pl], key); hk = key; }
@@ -1100,7 +1122,11 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 // hits on full lists, one at a time, the whole wave on each (out of line: rare, and its registers would
                 // otherwise count against the loop above)
                 const unsigned long long pending = __ballot(over_key != ~0ull);
-                if (pending) full_list_insert(pending, over_key, pl, lds_keys, spill_keys, thr_keys, P.cap, KL);
+                if (pending) {
+                  wave_lds_handoff();  // the lists it scans were appended to by any lane
+                  full_list_insert(pending, over_key, pl, lds_keys, spill_keys, thr_keys, P.cap, KL);
+                  wave_lds_handoff();
+                }
               }
             }
           }
@@ -1144,6 +1170,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(need ? cnt : 0));
       const int j = keys.compact(need, cnt, maxcnt, hide_key);
       if (need) n_rel = j;
+      wave_lds_handoff();  // the cross-lane sorts below read these lists
     }
     if (!pix_live) n_rel = 0;
     {
@@ -1298,6 +1325,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         }
       }
       // the pixels whose lists went through a cross-lane sort pick up their new lengths
+      wave_lds_handoff();
       if (n_rel > kDeep && n_rel <= (BIGK ? 128 : 64)) n_rel = s_cnt[lane];
     }
     const int m = min(n_rel, K);  // layers of this pixel that matter, front to back in slots [0, m): the K nearest
@@ -1307,6 +1335,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     int* s_pre = s_fpre_all + wave * kPreStride;
     unsigned char* marks = reinterpret_cast<unsigned char*>(s_pre + 68);
     s_pre[lane] = pre;
+    wave_lds_handoff();
     // the staging buffers are dead once the fine step is over (every wave is past its last barrier): this wave's
     // slice of them carries the batch's (alpha, r, g, b) from the lanes that computed them to the pixels' owners
     float4* s_res = s_rec + wave * 160;                      // 128 float4: (alpha, r, g, b) of a round's items
@@ -1327,9 +1356,11 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int b0 = base + 64 * u;
+        wave_lds_handoff();  // (the marks of the previous pass have been read)
         marks[lane] = 0;
         const int l0 = 63 - __builtin_clzll(__ballot(m > 0 && pre <= b0));
         if (m > 0 && pre > b0 && pre < b0 + 64) marks[pre - b0] = (unsigned char)(lane + 1);
+        wave_lds_handoff();
         il[u] = wave_scan_max(lane == 0 ? l0 + 1 : (int)marks[lane]) - 1;
         act[u] = b0 + lane < total;
         ik[u] = min(b0 + lane, total - 1) - s_pre[il[u]];
@@ -1369,6 +1400,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
         if (P.use_amb) { vr[u] *= P.amb[0]; vg[u] *= P.amb[1]; vb[u] *= P.amb[2]; }
         s_res[64 * u + lane] = make_float4(va[u], vr[u], vg[u], vb[u]);
       }
+      wave_lds_handoff();
       // owners composite their items of this round, in depth order, and leave the transmittance in front of each
       const int s0 = max(pre, base), e0 = min(pre + m, base + 64 * U);
       const int nloop = __builtin_amdgcn_readfirstlane(wave_max(max(e0 - s0, 0)));
@@ -1382,6 +1414,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       }
       // the layer rows for the backward, written by the lanes that computed them: 64 consecutive 32-byte rows per
       // store instruction
+      wave_lds_handoff();
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (act[u]) {
@@ -1875,6 +1908,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     //      batches: in any one batch the 64 lanes then sit in 64 different neighbourhoods of the group, so fewer of
     //      them meet on the same face / texel -- an LDS atomic costs ~12 clocks per extra lane on its address.  A row
     //      names its pixel, so an item is one 16-byte load away; the next item's row is fetched a batch ahead.
+    wave_lds_handoff();  // step (a)'s float per row was written by another lane of this wave (same tile, global memory)
     const int nbatch = (hi - lo + 63) >> 6;
     const int item0 = lo + lane * nbatch;
     const float own_px = pix_to_ndc(W - 1 - x, W, H), own_py = pix_to_ndc(H - 1 - y, H, W);
