@@ -1993,12 +1993,18 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       if (P.gfv && gd != 0.0f) {
         // d(signed dist)/d(ends of the nearest edge); first minimal edge wins ties
         const float gs = ev.inside ? -gd : gd;
-        if (ev.d01 <= ev.d02 && ev.d01 <= ev.d12)
-          seg_bwd(px, py, fc.v0x, fc.v0y, fc.v1x, fc.v1y, gs, o[0], o[1], o[2], o[3]);
-        else if (ev.d02 <= ev.d01 && ev.d02 <= ev.d12)
-          seg_bwd(px, py, fc.v0x, fc.v0y, fc.v2x, fc.v2y, gs, o[0], o[1], o[4], o[5]);
-        else
-          seg_bwd(px, py, fc.v1x, fc.v1y, fc.v2x, fc.v2y, gs, o[2], o[3], o[4], o[5]);
+        // the edge's ends picked by selects, ONE evaluation, the results dealt to their corners by selects: the lanes
+        // of a wave sit on all three edges, and three divergent copies of the segment code ran one after the other
+        const bool e01 = ev.d01 <= ev.d02 && ev.d01 <= ev.d12;
+        const bool e02 = !e01 && ev.d02 <= ev.d01 && ev.d02 <= ev.d12;
+        const bool from0 = e01 || e02;
+        const float ax = from0 ? fc.v0x : fc.v1x, ay = from0 ? fc.v0y : fc.v1y;
+        const float bx = e01 ? fc.v1x : fc.v2x, by = e01 ? fc.v1y : fc.v2y;
+        float gax = 0.0f, gay = 0.0f, gbx = 0.0f, gby = 0.0f;
+        seg_bwd(px, py, ax, ay, bx, by, gs, gax, gay, gbx, gby);
+        o[0] += from0 ? gax : 0.0f; o[1] += from0 ? gay : 0.0f;
+        o[2] += from0 ? (e01 ? gbx : 0.0f) : gax; o[3] += from0 ? (e01 ? gby : 0.0f) : gay;
+        o[4] += e01 ? 0.0f : gbx; o[5] += e01 ? 0.0f : gby;
       }
       if (P.gfv && (wgt != 0.0f || gd != 0.0f)) {
         const int h = lds_claim(s_ftag, fid & (kFaceSlots - 1), fid, kFaceSlots);
