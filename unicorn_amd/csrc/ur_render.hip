@@ -1799,7 +1799,10 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   constexpr int kTexSlots = 16 * kTexCols;
   __shared__ int s_ftag[kFaceSlots];
   __shared__ int s_ttag[kTexSlots];
-  __shared__ double s_fval[kFaceSlots * 6];
+  // six sums per face slot, seven doubles apart: with a stride of six (12 banks, gcd 4 with the 64) one add instruction
+  // could reach only every second bank pair
+  constexpr int kFaceStride = 7;
+  __shared__ double s_fval[kFaceSlots * kFaceStride];
   __shared__ double s_tval[kTexSlots * 3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = P.H, W = P.W, K = P.K;
@@ -1837,7 +1840,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   if (!__syncthreads_or(total > 0)) return;  // nothing rendered in this bin
   const int lo = 0, hi = total;
   for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
-  for (int i = tid; i < kFaceSlots * 6; i += 256) s_fval[i] = 0.0;
+  for (int i = tid; i < kFaceSlots * kFaceStride; i += 256) s_fval[i] = 0.0;
   for (int i = tid; i < kTexSlots; i += 256) s_ttag[i] = -1;
   for (int i = tid; i < kTexSlots * 3; i += 256) s_tval[i] = 0.0;
   __syncthreads();
@@ -2011,7 +2014,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
         if (h >= 0) {
 #pragma unroll
           for (int i = 0; i < 6; ++i)
-            if (o[i] != 0.0f) atomicAdd(&s_fval[h * 6 + i], (double)o[i]);
+            if (o[i] != 0.0f) atomicAdd(&s_fval[h * kFaceStride + i], (double)o[i]);
         } else {
 #pragma unroll
           for (int i = 0; i < 6; ++i)
@@ -2026,7 +2029,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     for (int i = tid; i < kFaceSlots * 6; i += 256) {
       const int slot = i / 6, c = i - slot * 6;
       const int tag = s_ftag[slot];
-      const float v = (float)s_fval[i];
+      const float v = (float)s_fval[slot * kFaceStride + c];
       if (tag >= 0 && v != 0.0f) atomicAdd(face_sum(tag, c), v);
     }
   if (gmap)
