@@ -698,11 +698,31 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   const int by = b / P.nbx, bx = b - by * P.nbx;
   const int H = P.H, W = P.W, K = P.K, KL = P.KL;
 
+  if (MODE == 2 && (sched & kEmptyBin)) {
+    // a bin the schedule flagged empty (no face box reaches it; half the bins of a batch of centred objects): its
+    // pixels are background and its layer counts zero -- written straight away, none of the set-up below
+    const int ex = bx * BW + (wave & 1) + 2 * (lane & 7), ey = by * BH + (wave >> 1) + 2 * (lane >> 3);
+    if (bx * BW + (wave & 1) < W && by * BH + (wave >> 1) < H) {
+      const int64_t etile = (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
+      P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + etile * 64 + lane] = 0;
+      if (ex < W && ey < H) {
+        const int64_t hw = (int64_t)H * W;
+        float* img = P.image + (int64_t)n * 4 * hw + (int64_t)ey * W + ex;
+        img[0] = 0.0f + 1.0f * 1.0f * P.bg[0];
+        img[hw] = 0.0f + 1.0f * 1.0f * P.bg[1];
+        img[2 * hw] = 0.0f + 1.0f * 1.0f * P.bg[2];
+        img[3 * hw] = 1.0f - 1.0f;
+      }
+    }
+    return;
+  }
+
   // bin extents in pixel-centre NDC (columns x0..x1, rows y0..y1, clamped to the image)
   const int bx0 = bx * BW, by0 = by * BH;
   const int bx1 = min(W, bx0 + BW) - 1, by1 = min(H, by0 + BH) - 1;
-  const float bxc_hi = pix_to_ndc(W - 1 - bx0, W, H), bxc_lo = pix_to_ndc(W - 1 - bx1, W, H);
-  const float byc_hi = pix_to_ndc(H - 1 - by0, H, W), byc_lo = pix_to_ndc(H - 1 - by1, H, W);
+  const NdcAxis ax_x = ndc_axis(W, H), ax_y = ndc_axis(H, W);
+  const float bxc_hi = pix_to_ndc(W - 1 - bx0, ax_x), bxc_lo = pix_to_ndc(W - 1 - bx1, ax_x);
+  const float byc_hi = pix_to_ndc(H - 1 - by0, ax_y), byc_lo = pix_to_ndc(H - 1 - by1, ax_y);
 
   // this wave's 64 pixels.  MODE 1 (tile lists): the 8x8 tile (wave & 1, wave >> 1) of the bin.  Otherwise every
   // second column / row of the bin starting at (wave & 1, wave >> 1): the four waves of a workgroup then see almost
@@ -711,13 +731,13 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   const int tx0 = bx0 + (wave & 1) * (MODE == 1 ? kTile : 1), ty0 = by0 + (wave >> 1) * (MODE == 1 ? kTile : 1);
   const bool tile_live = (tx0 < W) && (ty0 < H);
   const int tx1 = min(W, tx0 + xs * (kTile - 1) + 1) - 1, ty1 = min(H, ty0 + xs * (kTile - 1) + 1) - 1;
-  const float txc_hi = pix_to_ndc(W - 1 - tx0, W, H), txc_lo = pix_to_ndc(W - 1 - max(tx1, tx0), W, H);
-  const float tyc_hi = pix_to_ndc(H - 1 - ty0, H, W), tyc_lo = pix_to_ndc(H - 1 - max(ty1, ty0), H, W);
+  const float txc_hi = pix_to_ndc(W - 1 - tx0, ax_x), txc_lo = pix_to_ndc(W - 1 - max(tx1, tx0), ax_x);
+  const float tyc_hi = pix_to_ndc(H - 1 - ty0, ax_y), tyc_lo = pix_to_ndc(H - 1 - max(ty1, ty0), ax_y);
 
   // this lane's pixel
   const int x = tx0 + xs * (lane & 7), y = ty0 + xs * (lane >> 3);
   const bool pix_live = (x < W) && (y < H);
-  const float px = pix_to_ndc(W - 1 - x, W, H), py = pix_to_ndc(H - 1 - y, H, W);
+  const float px = pix_to_ndc(W - 1 - x, ax_x), py = pix_to_ndc(H - 1 - y, ax_y);
 
   // index of this wave's pixel group in layers / spill / tile lists
   const int64_t tile_id = (MODE == 1) ? ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * ((W + 7) / 8) + (tx0 >> 3)
@@ -1384,8 +1404,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       Bilin bl[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float qx = pix_to_ndc(W - 1 - (tx0 + xs * (il[u] & 7)), W, H);
-        const float qy = pix_to_ndc(H - 1 - (ty0 + xs * (il[u] >> 3)), H, W);
+        const float qx = pix_to_ndc(W - 1 - (tx0 + xs * (il[u] & 7)), ax_x);
+        const float qy = pix_to_ndc(H - 1 - (ty0 + xs * (il[u] >> 3)), ax_y);
         Eval ev;
         eval_face(fc[u], qx, qy, P.blur, P.clip != 0, ev);
         va[u] = layer_alpha(ev.sd, true, P.sigma, P.mode);
