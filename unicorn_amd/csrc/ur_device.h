@@ -123,17 +123,16 @@ __device__ __forceinline__ bool eval_face(const Face& f, float px, float py, flo
     c0 = div_by(c0, s, ys); c1 = div_by(c1, s, ys); c2 = div_by(c2, s, ys);
   }
   float pz = c0 * f.z0 + c1 * f.z1 + c2 * f.z2;
-  if (pz < 0.0f) return false;
+  const bool front = !(pz < 0.0f);  // (no early exit: a face behind the camera is rare, a branch per pair is not free)
   pz = pz + 0.0f;  // -0 -> +0: depth keys are compared as unsigned bit patterns
   o.d01 = seg_dist(px, py, f.v0x, f.v0y, f.v1x, f.v1y, d01x, d01y, f.l01, f.il01);
   o.d02 = seg_dist(px, py, f.v0x, f.v0y, f.v2x, f.v2y, -d20x, -d20y, f.l02, f.il02);
   o.d12 = seg_dist(px, py, f.v1x, f.v1y, f.v2x, f.v2y, f.d12x, f.d12y, f.l12, f.il12);
   const float dist = min_s(min_s(o.d01, o.d02), o.d12);
   o.inside = (o.w0 > 0.0f) && (o.w1 > 0.0f) && (o.w2 > 0.0f);
-  if (!o.inside && dist >= blur) return false;
   o.pz = pz; o.sd = o.inside ? -dist : dist;
   o.c0 = c0; o.c1 = c1; o.c2 = c2;
-  return true;
+  return front && (o.inside || !(dist >= blur));
 }
 
 // ---- texture sampling: grid_sample(flip_y(map), 2uv-1, bilinear, align_corners=True, padding 'border') ----------
