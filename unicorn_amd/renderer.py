@@ -78,6 +78,10 @@ class PointLights(AmbientLights):
         self.diffuse_color, self.specular_color, self.location = diffuse_color, specular_color, location
 
 
+def _f32(t):
+    return t if t.dtype is torch.float32 else t.float()
+
+
 _rgb3_seen = {}
 
 
@@ -116,6 +120,7 @@ class MeshRasterizer(nn.Module):
         self.cameras = cameras
         self.raster_settings = raster_settings if raster_settings is not None else RasterizationSettings()
         self._idx_cache = {}
+        self._faces_cache = {}
 
     def to(self, device):
         if self.cameras is not None:
@@ -128,6 +133,21 @@ class MeshRasterizer(nn.Module):
             first = torch.arange(N, dtype=torch.int64, device=device) * F
             self._idx_cache[key] = (first, torch.full((N,), F, dtype=torch.int64, device=device))
         return self._idx_cache[key]
+
+    def _shared_faces(self, faces):
+        """(N,F,3) faces -> what the one-call path takes: the (F,3) table when the batch is an expanded view of one
+        topology (unicorn.py:86-93 builds it so), else the contiguous (N,F,3).  The reference hands over the same
+        expanded tensor every step: the table view is kept for as long as that storage is (no tensor op per step)."""
+        if faces.stride(0) != 0:
+            return faces.contiguous()
+        key = (faces.data_ptr(), faces._version, faces.shape, faces.device)
+        hit = self._faces_cache.get(key)
+        if hit is None:
+            if len(self._faces_cache) > 8:
+                self._faces_cache.clear()
+            # (the entry keeps `faces` alive, so its address cannot pass to another tensor meanwhile)
+            hit = self._faces_cache[key] = (faces[0].contiguous(), faces)
+        return hit[0]
 
     def transform(self, meshes, R, T):
         """-> face_verts (sum F_n, 3, 3) in NDC (z = view depth), mesh_first_face, mesh_num_faces"""
@@ -195,11 +215,11 @@ class LayeredShader(nn.Module):
             sx, sy = rasterizer.cameras.focal_scale()
             verts, faces = meshes.verts_padded(), meshes.faces_padded()
             N, Fn = faces.shape[:2]
-            faces = faces[0] if faces.stride(0) == 0 else faces
+            faces = rasterizer._shared_faces(faces)
             first, nf = rasterizer._mesh_index(N, Fn, verts.device)
-            return ops.render_meshes(verts.float(), tex.maps_padded().float(), R.float(), T.float(), faces.contiguous(),
+            return ops.render_meshes(_f32(verts), _f32(tex.maps_padded()), _f32(R), _f32(T), faces,
                                      sx, sy, first, nf, rs.image_size, rs.blur_radius, rs.faces_per_pixel,
-                                     rs.clip_barycentric_coords, face_uvs.float(), shared, bp.sigma,
+                                     rs.clip_barycentric_coords, _f32(face_uvs), shared, bp.sigma,
                                      _rgb3(bp.background_color), ambient, self.blend_mode(bp))
         face_verts, first, nf = rasterizer.transform(meshes, R, T)
         return ops.render_layered(face_verts, tex.maps_padded().float(), first, nf, rs.image_size, rs.blur_radius,
@@ -304,11 +324,12 @@ class MeshRenderer(nn.Module):
         return self
 
     def forward(self, meshes, **kwargs):
-        if self.fused and isinstance(self.shader, LayeredShader) and self.shader.shading_type == 'raw' \
-                and isinstance(meshes.textures, TexturesUV) and not self.shader.debug:
-            return self.shader.render_fused(self.rasterizer, meshes, **kwargs)
+        shader = self.shader  # (a sub-module: every `self.shader` goes through nn.Module.__getattr__)
+        if self.fused and isinstance(shader, LayeredShader) and shader.shading_type == 'raw' \
+                and isinstance(meshes.textures, TexturesUV) and not shader.debug:
+            return shader.render_fused(self.rasterizer, meshes, **kwargs)
         fragments = self.rasterizer(meshes, **kwargs)
-        return self.shader(fragments, meshes, **kwargs)
+        return shader(fragments, meshes, **kwargs)
 
 
 class VizMeshRenderer(MeshRenderer):
