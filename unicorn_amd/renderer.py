@@ -107,6 +107,8 @@ def _rgb3(c):
                 except TypeError:
                     pass
             return out
+        if torch.is_tensor(flat):  # a tensor wrapped in one-element tuples / lists
+            c = flat
     t = torch.as_tensor(c, dtype=torch.float32).detach().cpu().flatten()
     assert t.numel() == 3, "colour must have 3 components"
     return tuple(float(v) for v in t)
