@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, sys
 tag, wl, name = sys.argv[1:4]
 src = f"gpurun_out/{tag}_{wl}"
 KERNELS = {"k_raster<2": "k_raster<2>", "k_render_bwd": "k_render_bwd", "k_project_prep_mesh": "k_project_prep_mesh",
-           "k_bin_order": "k_bin_order", "k_project_faces_bwd_mesh": "k_project_faces_bwd_mesh",
+           "k_bin_order": "k_bin_order", "k_bin_sum": "k_bin_sum", "k_project_faces_bwd_mesh": "k_project_faces_bwd_mesh",
            "k_camera_bwd_mesh": "k_camera_bwd_mesh",
            "k_face_prep": "k_face_prep", "k_project_faces(": "k_project_faces"}
 
