@@ -1206,7 +1206,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     // network after all, and the cross-lane sorts get shorter (5120-face meshes +3 %, 20480 faces / K=100 +3 %).  Short
     // lists drop their hidden entries on the way through the network: they are replaced by the all-ones pad, which
     // sorts to the end.
-    if (__any(hide_key != ~0ull && cnt > kDeep)) {
+    // (only when the wave holds many such lists: the drop is a lockstep loop over the longest of them, part of it
+    // through the global spill area; a few long lists cost less going straight to the cross-lane sorts, which drop
+    // hidden entries as well -- 128x128 -1 %, the 192-image pose step -3 %, dense meshes unchanged)
+    if (__popcll(__ballot(hide_key != ~0ull && cnt > kDeep)) > 16) {
       const bool need = hide_key != ~0ull && cnt > kDeep;
       const int maxcnt = __builtin_amdgcn_readfirstlane(wave_max(need ? cnt : 0));
       const int j = keys.compact(need, cnt, maxcnt, hide_key);
