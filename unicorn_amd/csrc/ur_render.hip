@@ -1538,9 +1538,14 @@ constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4
 // leaving LDS made the in-loop compactions and the lane = pixel full-list route dear; with both gone (appends beyond
 // the cap are fire-and-forget stores) occupancy wins everywhere: 5120-face meshes 286 -> 250 us, 20480 faces at
 // 256^2 / K=100 1.15 -> 0.85 ms.
-// the fused backward's table shapes are picked by the mesh's face density on the image (see k_render_bwd)
-bool render_bwd_dense(int64_t total_faces, int N, int H, int W) {
-  return (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W) >= 0.2;
+// The fused backward's table shapes (see k_render_bwd): more face slots and fewer texel slots when the mesh is dense
+// on the image (>= 0.2 faces per pixel) AND a bin sees few texels (texture no finer than half the image's resolution:
+// a 16x16-pixel bin then spans at most ~8x8 texels of an object that fills the frame).  Face density alone sent 64x64
+// images under 64x64 textures -- a texel per pixel, 256 texels per bin -- to the 256-slot texel table: a quarter of the
+// backward's time went to collisions falling through to global atomics (pose step 192 x 64x64: 94.7 -> 71.2 us).
+bool render_bwd_dense(int64_t total_faces, int N, int H, int W, int Ht, int Wt) {
+  const bool dense = (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W) >= 0.2;
+  return dense && (int64_t)Ht * Wt * 4 <= (int64_t)H * W;
 }
 
 // The fragment-writing build (lane = pixel, keep-the-K-smallest in place) still prefers its lists in LDS on dense
@@ -1793,7 +1798,8 @@ __global__ void __launch_bounds__(256) k_raster_bwd(const float* __restrict__ fv
 //   16 x TC texel slots (x 3 sums), home slot = torus over (texel row, texel column): the texels of one contiguous
 //   footprint never collide.
 // Coarse meshes put few faces but long strips of texels into a bin (256 / 512: 27 KB), fine meshes the other way
-// round (512 / 256: 33 KB); the host picks by the mesh's face density on the image (render_bwd_dense).
+// round (512 / 256: 37 KB); the host picks by the mesh's face density on the image and the texels a bin sees
+// (render_bwd_dense).
 constexpr int kProbes = 3;       // slots tried per key (open addressing) before a contribution goes to global memory
 constexpr int kProbeStep = 73;   // odd, and far from the torus neighbours that a footprint fills next
 
@@ -3061,7 +3067,7 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
   if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
   {
     ProfScope prof(UR_PROFILE_RENDER_BWD, (hipStream_t)stream);
-    if (render_bwd_dense(total_faces, N, H, W))
+    if (render_bwd_dense(total_faces, N, H, W, Ht, Wt))
       hipLaunchKernelGGL((k_render_bwd<512, 16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
     else
       hipLaunchKernelGGL((k_render_bwd<256, 32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
