@@ -50,6 +50,8 @@ WORKLOADS = {
     "C2_B32_64x64_K50_ico3": dict(B=32, level=3, img=64, K=50, tex=64),
     "C4b_B64_128x128_K50_ico4": dict(B=64, level=4, img=128, K=50, tex=64),
     "C2p_B192_64x64_K50_ico3": dict(B=192, level=3, img=64, K=50, tex=64),      # pose step of cfg2: 32 x 6 candidates
+    "C3_B32_64x64_K25_ico3": dict(B=32, level=3, img=64, K=25, tex=64),         # cfg3: faces_per_pixel 25
+    "C3p_B192_64x64_K25_ico3": dict(B=192, level=3, img=64, K=25, tex=64),
     "C5_B16_256x256_K100_ico5": dict(B=16, level=5, img=256, K=100, tex=64),
     "C5_B128_256x256_K100_ico5": dict(B=128, level=5, img=256, K=100, tex=64),  # cfg[4] at its per-GPU shard size
 }
