@@ -441,8 +441,13 @@ class Renderer(nn.Module):
     def compute_vertex_visibility(self, meshes, R, T):
         """(N,V) bool: vertices of faces that own at least one pixel of the hard 2x-supersampled raster
         (renderer.py:105-116)."""
-        fragments = self.viz_renderer.rasterizer(meshes, R=R, T=T)
-        p2f = fragments.pix_to_face_i32
+        rasterizer = self.viz_renderer.rasterizer
+        rs = rasterizer.raster_settings
+        face_verts, first, nf = rasterizer.transform(meshes, R, T)
+        # only the face indices are wanted: depths, barycentrics and distances are not written at all
+        p2f = native.rasterize_meshes(face_verts.detach(), first, nf, rs.image_size, rs.blur_radius, rs.faces_per_pixel,
+                                      rs.clip_barycentric_coords, rs.cull_backfaces, want_zbuf=False, want_bary=False,
+                                      want_dists=False)[0]
         packed_faces = meshes.faces_packed()
         n_verts = meshes.verts_packed().shape[0]
         face_visible = torch.zeros(packed_faces.shape[0] + 1, dtype=torch.bool, device=p2f.device)
