@@ -26,24 +26,36 @@ def _make(device):
     return model, imgs
 
 
-def _rank_main(rank, world, port, out_path):
+def _rank_main(rank, world, rdzv_path, out_path):
     import faulthandler
     import time
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     from examples.train_step import train_steps
     from unicorn_amd import dist as udist
     # a rank that is still busy after 80 s says where (all threads) before the parent's limit kills it
     faulthandler.dump_traceback_later(80, exit=False)
+    t_start = time.perf_counter()
+
+    def mark(what):  # progress notes the parent quotes if the ranks overrun
+        with open(f"{out_path}.rank{rank}.log", "a") as f:
+            f.write(f"{time.perf_counter() - t_start:7.1f} s  {what}\n")
+    mark("started")
     udist.isolate_miopen_cache(rank)  # the ranks share the box: each gets its own MIOpen database / kernel cache
     t0 = time.perf_counter()
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's own temporary directory: no store port that another process on the
+    # host could hold (a run of the suite once sat in this call until the bounded wait below gave up)
+    dist.init_process_group("gloo", init_method="file://" + rdzv_path, rank=rank, world_size=world)
+    mark("process group up")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     model, imgs = _make(dev)
+    mark("model on the GPU")
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
+    mark("DDP wrapper built")
     losses = train_steps(ddp, imgs[rank * PER_RANK:(rank + 1) * PER_RANK], STEPS)
+    mark("training steps done")
     print(f"rank {rank}: {STEPS} DDP steps (MIOpen convolutions) after {time.perf_counter() - t0:.1f} s", flush=True)
     t = torch.tensor(losses, device=dev)
     dist.all_reduce(t)
@@ -60,15 +72,20 @@ def test_two_rank_ddp_step_equals_single_process_training():
     from examples.train_step import train_steps
     with tempfile.TemporaryDirectory() as tmp:
         out_path = os.path.join(tmp, "rank0.pt")
-        port = 29500 + (os.getpid() % 400)
-        ctx = mp.spawn(_rank_main, args=(2, port, out_path), nprocs=2, join=False)
+        ctx = mp.spawn(_rank_main, args=(2, os.path.join(tmp, "rendezvous"), out_path), nprocs=2, join=False)
         for _ in range(100):                       # bounded wait: never hang the suite on a stuck rank
             if ctx.join(timeout=1.0):
                 break
         else:
             for p in ctx.processes:
                 p.kill()
-            pytest.fail("DDP ranks did not finish within 100 s")
+            notes = []
+            for r in range(2):
+                try:
+                    notes.append(f"rank {r}:\n" + open(f"{out_path}.rank{r}.log").read())
+                except OSError:
+                    notes.append(f"rank {r}: no progress note")
+            pytest.fail("DDP ranks did not finish within 100 s\n" + "\n".join(notes))
         # the same training in this process on the whole batch (after the ranks), MIOpen convolutions on both sides
         model, imgs = _make(torch.device("cuda", 0))
         losses = train_steps(model, imgs, STEPS)
