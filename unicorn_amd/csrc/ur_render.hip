@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(256) k_bin_sum(int* __restrict__ binload, int 
   }
   p[0] = sum;
 }
-constexpr int kBinSumParts = 16;  // from this many parts per mesh on, k_bin_sum runs before the sort
+constexpr int kBinSumParts = 32;  // from this many parts per mesh on, k_bin_sum runs before the sort (at 20 parts --
+                                  // 5120-face meshes -- the two kernels together take what the sort alone did)
 
 // `parts` partial counts per (mesh, bin), laid out [mesh][part][bin]; parts == 1 with mesh_stride > bins_per_mesh: the
 // totals k_bin_sum left in the part-0 slots of that layout
