@@ -43,6 +43,7 @@ def _rank_main(rank, world, rdzv_path, out_path):
             f.write(f"{time.perf_counter() - t_start:7.1f} s  {what}\n")
     mark("started")
     udist.isolate_miopen_cache(rank)  # the ranks share the box: each gets its own MIOpen database / kernel cache
+    udist.gloo_on_loopback()          # no host-name lookups for gloo's sockets (the box's name does not resolve)
     t0 = time.perf_counter()
     # rendezvous through a file in the test's own temporary directory: no store port that another process on the
     # host could hold (a run of the suite once sat in this call until the bounded wait below gave up)

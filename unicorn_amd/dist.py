@@ -27,11 +27,22 @@ def isolate_miopen_cache(rank):
             os.environ[var] = path
 
 
+def gloo_on_loopback():
+    """Single-node gloo jobs (CPU tests, the one-GPU rehearsal of `bench.py --gpus N`): pin gloo's sockets to the
+    loopback interface unless the caller chose one.  Left alone gloo looks its interface up through the HOST NAME, and
+    a container's host name may not resolve (c10d warns "hostname of the client socket cannot be retrieved"): each
+    failed lookup waits on the resolver.  Does nothing when `lo` does not exist.  RCCL is left alone."""
+    if "GLOO_SOCKET_IFNAME" not in os.environ and os.path.isdir("/sys/class/net/lo"):
+        os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+
+
 def init(backend=None):
     """-> (rank, local_rank, world).  backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU."""
     rank, local, world = env_world()
     if world > 1 and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "gloo" and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+            gloo_on_loopback()
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend, **kw)
     return rank, local, world
