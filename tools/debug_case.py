@@ -1,0 +1,128 @@
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import orc
+from unicorn_amd import synth
+from unicorn_amd.renderer import Renderer
+from unicorn_amd.structures import Meshes, TexturesUV
+S = float(1.0 / np.tan(np.deg2rad(15.0)))
+N, level, H, W, K, sigma, clip_inside, scale, tex, seed = 4, 2, 96, 80, 1, 1e-3, True, 0.4, 64, 2191
+if len(sys.argv) > 1: K = int(sys.argv[1])
+sc = synth.make_scene(N, level=level, tex_size=tex, seed=seed, scale=scale)
+dev = torch.device("cuda", 0)
+cot = np.random.RandomState(seed).randn(N, 4, H, W).astype(np.float32)
+uvs = np.broadcast_to(sc["verts_uvs"].numpy()[None], (N,) + tuple(sc["verts_uvs"].shape)).copy()
+res = {}
+for dt in (np.float32, np.float64):
+    rimg, g = orc.render_fwd_bwd(sc["verts"].numpy(), sc["faces"].numpy(), sc["R"].numpy(), sc["T"].numpy(),
+                                 sc["maps"].numpy(), uvs, H, W, K, S, sigma=sigma, clip_inside=clip_inside, grad_image=cot, dtype=dt)
+    res[dt] = (rimg, g)
+for fused in (True, False):
+    rend = Renderer((H, W), cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=sigma, clip_inside=clip_inside).to(dev)
+    rend.renderer.fused = fused
+    verts = sc["verts"].to(dev).requires_grad_(True); maps = sc["maps"].to(dev).requires_grad_(True)
+    R = sc["R"].to(dev).requires_grad_(True); T = sc["T"].to(dev).requires_grad_(True)
+    fb = sc["faces"].to(dev)[None].expand(N, -1, -1); ub = sc["verts_uvs"].to(dev)[None].expand(N, -1, -1)
+    img = rend(Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub)), R, T)
+    img.backward(torch.from_numpy(cot).to(dev))
+    for dt in (np.float32, np.float64):
+        rimg, (gv, gR, gT, gm) = res[dt]
+        print("fused" if fused else "two-stage", dt.__name__, "image", float(np.abs(img.detach().cpu().numpy() - rimg).max()),
+              {n: float(np.abs(a.cpu().numpy() - b).max() / np.abs(b).max()) for n, a, b in
+               (("verts", verts.grad, gv), ("maps", maps.grad, gm), ("R", R.grad, gR), ("T", T.grad, gT))})
+g32, g64 = res[np.float32][1], res[np.float64][1]
+print("oracle f32 vs f64:", [float(np.abs(a - b).max() / np.abs(b).max()) for a, b in zip(g32, g64)])
+print("max |grad verts|", float(np.abs(g64[0]).max()))
+gv_gpu = verts.grad.cpu().numpy()
+gv64 = g64[0]; gv32 = g32[0]
+d = np.abs(gv_gpu - gv64)
+idx = np.dstack(np.unravel_index(np.argsort(-d.ravel())[:8], d.shape))[0]
+for n, v, c in idx:
+    print("mesh", n, "vert", v, "comp", c, "gpu", gv_gpu[n, v, c], "orc32", gv32[n, v, c], "orc64", gv64[n, v, c])
+# the raster stage alone: grad_face_verts from the fragment path vs oracle
+from unicorn_amd import native
+vn = orc.project_verts(sc["verts"].numpy(), sc["R"].numpy(), sc["T"].numpy(), S)
+faces = sc["faces"].numpy(); F = faces.shape[0]
+fv = np.stack([vn[n][faces] for n in range(N)]).reshape(-1, 3, 3).astype(np.float32)
+blur = orc.blur_radius_for(sigma)
+ref = orc.rasterize(fv, N, H, W, blur, K, clip_bary=True)
+rs = np.random.RandomState(1)
+gz = rs.randn(*ref[1].shape).astype(np.float32); gb = rs.randn(*ref[2].shape).astype(np.float32); gd = rs.randn(*ref[3].shape).astype(np.float32)
+want = orc.rasterize_backward(fv, ref[0], gz, gb, gd, True)
+want64 = orc.rasterize_backward(fv.astype(np.float64), ref[0], gz.astype(np.float64), gb.astype(np.float64), gd.astype(np.float64), True, dtype=np.float64)
+got = native.rasterize_meshes_backward(torch.from_numpy(fv).to(dev), torch.from_numpy(ref[0].astype(np.int32)).to(dev),
+                                       torch.from_numpy(gz).to(dev), torch.from_numpy(gb).to(dev), torch.from_numpy(gd).to(dev), True).cpu().numpy()
+print("raster backward alone: gpu vs orc32", float(np.abs(got - want).max() / np.abs(want).max()), "gpu vs orc64", float(np.abs(got - want64).max() / np.abs(want64).max()), "orc32 vs orc64", float(np.abs(want - want64).max() / np.abs(want64).max()), "max", float(np.abs(want64).max()))
+# shading + blend backward alone, on the oracle's fragments
+p2f, zb, bar, ds = ref
+mapsn = sc["maps"].numpy()
+fuv_shared = sc["verts_uvs"].numpy()[faces]                      # (F,3,2)
+fuv_packed = np.tile(fuv_shared, (N, 1, 1)).astype(np.float32)    # (N*F,3,2)
+mode = orc.blend_mode(sigma, clip_inside)
+for dt in (np.float32, np.float64):
+    tex_o = orc.sample_textures(mapsn, fuv_packed, p2f, bar, dtype=dt)
+    gcol, gdist = orc.layered_blend_bwd(tex_o, p2f, ds, cot, sigma, (1., 1., 1.), mode, dtype=dt)
+    gmaps_o, gbary_o = orc.sample_textures_bwd(mapsn, fuv_packed, p2f, bar, gcol, dtype=dt)
+    res[dt] = (gmaps_o, gbary_o, gdist)
+first = torch.arange(N, dtype=torch.int64, device=dev) * F
+gm, gb_, gd_ = native.shade_blend_backward(torch.from_numpy(cot).to(dev), torch.from_numpy(p2f.astype(np.int32)).to(dev),
+                                          torch.from_numpy(bar).to(dev), torch.from_numpy(ds).to(dev), sc["maps"].to(dev),
+                                          torch.from_numpy(fuv_shared.astype(np.float32)).to(dev), True, first, sigma, (1., 1., 1.), None, mode)
+for dt in (np.float32, np.float64):
+    o = res[dt]
+    print("shade+blend backward vs oracle", dt.__name__, "gmaps", float(np.abs(gm.cpu().numpy() - o[0]).max() / np.abs(o[0]).max()),
+          "gbary", float(np.abs(gb_.cpu().numpy() - o[1]).max() / np.abs(o[1]).max()), "gdists", float(np.abs(gd_.cpu().numpy() - o[2]).max() / np.abs(o[2]).max()))
+a, b = gb_.cpu().numpy(), res[np.float64][1]
+i = np.unravel_index(np.argmax(np.abs(a - b)), a.shape); print("worst gbary at", i, a[i], res[np.float32][1][i], b[i], "p2f", p2f[i[:4]], "bary", bar[i[:4]], "dist", ds[i[:4]])
+a, b = gd_.cpu().numpy(), res[np.float64][2]
+i = np.unravel_index(np.argmax(np.abs(a - b)), a.shape); print("worst gdist at", i, a[i], res[np.float32][2][i], b[i], "p2f", p2f[i], "bary", bar[i], "dist", ds[i])
+# camera backward alone: oracle's grad_face_verts of the raster stage (given the oracle's upstream grads)
+o32 = res[np.float32]
+gfv_o = orc.rasterize_backward(fv, p2f, np.zeros_like(zb), o32[1], o32[2], True)        # (NF,3,3) f32
+g_ndc = np.zeros((N, sc["verts"].shape[1], 3), np.float64)
+for n in range(N):
+    np.add.at(g_ndc[n], faces.reshape(-1), gfv_o[n * F:(n + 1) * F].reshape(-1, 3).astype(np.float64))
+for dt in (np.float32, np.float64):
+    res[dt] = orc.project_verts_bwd(sc["verts"].numpy(), sc["R"].numpy(), sc["T"].numpy(), S, g_ndc.astype(dt), dtype=dt)
+gv_, gR_, gT_ = native.project_faces_backward(sc["verts"].to(dev), sc["faces"].to(dev), sc["R"].to(dev), sc["T"].to(dev), S, S,
+                                              torch.from_numpy(gfv_o).to(dev))
+for dt in (np.float32, np.float64):
+    o = res[dt]
+    print("camera backward vs oracle", dt.__name__, [float(np.abs(a.cpu().numpy() - b).max() / np.abs(b).max()) for a, b in zip((gv_, gR_, gT_), o)])
+print("end-to-end oracle f32 grads vs composed f64 camera stage:", float(np.abs(g32[0] - res[np.float64][0]).max() / np.abs(g32[0]).max()))
+print("gpu end-to-end vs composed f64 camera stage:", float(np.abs(gv_gpu - res[np.float64][0]).max() / np.abs(g32[0]).max()))
+got2 = native.rasterize_meshes_backward(torch.from_numpy(fv).to(dev), torch.from_numpy(p2f.astype(np.int32)).to(dev),
+                                        None, torch.from_numpy(o32[1]).to(dev), torch.from_numpy(o32[2]).to(dev), True).cpu().numpy()
+gfv64 = orc.rasterize_backward(fv.astype(np.float64), p2f, np.zeros_like(zb, dtype=np.float64), o32[1].astype(np.float64), o32[2].astype(np.float64), True, dtype=np.float64)
+print("raster backward on the actual upstream grads: gpu vs orc32", float(np.abs(got2 - gfv_o).max() / np.abs(gfv_o).max()),
+      "gpu vs orc64", float(np.abs(got2 - gfv64).max() / np.abs(gfv64).max()), "orc32 vs orc64", float(np.abs(gfv_o - gfv64).max() / np.abs(gfv64).max()), "max", float(np.abs(gfv64).max()))
+i = np.unravel_index(np.argmax(np.abs(got2 - gfv64)), got2.shape); f = i[0]
+print("worst face", f, "(mesh", f // F, "local", f % F, ") verts", faces[f % F], "gpu", got2[f].ravel(), "orc32", gfv_o[f].ravel(), "orc64", gfv64[f].ravel())
+npx = int((p2f == f).sum()); print("pixels of that face:", npx, "face_verts", fv[f].ravel())
+outg = native.rasterize_meshes(torch.from_numpy(fv).to(dev), first, torch.full((N,), F, dtype=torch.int64, device=dev), (H, W), blur, K, True)
+p2g, zbg, barg, dsg = [o.cpu().numpy() for o in outg]
+print("fragments equal as floats:", np.array_equal(p2g, p2f.astype(np.int32)), np.array_equal(zbg, zb), np.array_equal(barg, bar), np.array_equal(dsg, ds),
+      "; sign-bit differences: bary", int((np.signbit(barg) != np.signbit(bar)).sum()), "dists", int((np.signbit(dsg) != np.signbit(ds)).sum()), "zbuf", int((np.signbit(zbg) != np.signbit(zb)).sum()))
+# GPU projection vs the oracle's
+fvg = native.project_faces(sc["verts"].to(dev), sc["faces"].to(dev), sc["R"].to(dev), sc["T"].to(dev), S, S).cpu().numpy()
+print("projected corners bit-identical:", np.array_equal(fvg.view(np.int32), fv.view(np.int32)), "max diff", float(np.abs(fvg - fv).max()))
+gfv_mix = orc.rasterize_backward(fv, p2f, np.zeros_like(zb), gb_.cpu().numpy(), gd_.cpu().numpy(), True)
+print("oracle raster backward fed the GPU's gbary / gdists: face 609", gfv_mix[609].ravel(), "vs fed the oracle's", gfv_o[609].ravel())
+pix = np.argwhere(p2f[..., 0] == 609)
+for n_, y_, x_ in pix:
+    print("  pixel", n_, y_, x_, "gbary gpu", gb_.cpu().numpy()[n_, y_, x_, 0], "orc", o32[1][n_, y_, x_, 0], "gdist gpu", gd_.cpu().numpy()[n_, y_, x_, 0], "orc", o32[2][n_, y_, x_, 0], "bary", bar[n_, y_, x_, 0], "dist", ds[n_, y_, x_, 0])
+from unicorn_amd import ops
+v_t = sc["verts"].to(dev).requires_grad_(True); R_t = sc["R"].to(dev).requires_grad_(True); T_t = sc["T"].to(dev).requires_grad_(True)
+m_t = sc["maps"].to(dev).requires_grad_(True)
+fv_t = ops.project_faces(v_t, sc["faces"].to(dev), R_t, T_t, S, S); fv_t.retain_grad()
+nf_t = torch.full((N,), F, dtype=torch.int64, device=dev)
+fr = ops.rasterize(fv_t, first, nf_t, (H, W), blur, K, True)
+img2 = ops.shade_blend(fr[0], fr[2], fr[3], m_t, torch.from_numpy(fuv_shared.astype(np.float32)).to(dev), True, first, sigma, (1., 1., 1.), None, mode)
+img2.backward(torch.from_numpy(cot).to(dev))
+g_gpu = fv_t.grad.cpu().numpy()
+dd = np.abs(g_gpu - gfv_o).reshape(N * F, -1).max(1)
+top = np.argsort(-dd)[:5]
+print("GPU autograd chain: grad_face_verts vs oracle32, rel", float(np.abs(g_gpu - gfv_o).max() / np.abs(gfv_o).max()))
+for f_ in top:
+    print("  face", f_, "verts", faces[f_ % F], "pixels", int((p2f == f_).sum()), "gpu", g_gpu[f_].ravel()[[0,1,3,4,6,7]], "orc32", gfv_o[f_].ravel()[[0,1,3,4,6,7]], "orc64", gfv64[f_].ravel()[[0,1,3,4,6,7]])
+print("verts grad of this chain vs e2e oracle:", float(np.abs(v_t.grad.cpu().numpy() - g32[0]).max() / np.abs(g32[0]).max()))
