@@ -1,3 +1,6 @@
+"""Stage-by-stage comparison with the oracle of the one random scene whose vertex gradients differ by more than 1e-4
+(run by name; not collected): every stage alone matches, the end-to-end difference is float32 noise on a sliver face
+(DESIGN.md 3)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
