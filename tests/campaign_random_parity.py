@@ -21,12 +21,22 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-20))
 
 
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"  # finer meshes, larger images, K beyond 64 (the long-list code)
+
+
 def one_case(rng, idx):
-    N = int(rng.integers(1, 5))
-    level = int(rng.integers(1, 4))
-    H = int(rng.choice([16, 24, 32, 40, 48, 64, 72, 96]))
-    W = H if rng.random() < 0.6 else int(rng.choice([16, 24, 32, 40, 56, 64, 80]))
-    K = int(rng.choice([1, 3, 8, 10, 25, 50, 70]))
+    if BIG:
+        N = int(rng.integers(1, 3))
+        level = int(rng.choice([3, 4]))
+        H = int(rng.choice([96, 128, 160]))
+        W = H if rng.random() < 0.6 else int(rng.choice([80, 112, 144]))
+        K = int(rng.choice([50, 100, 130]))
+    else:
+        N = int(rng.integers(1, 5))
+        level = int(rng.integers(1, 4))
+        H = int(rng.choice([16, 24, 32, 40, 48, 64, 72, 96]))
+        W = H if rng.random() < 0.6 else int(rng.choice([16, 24, 32, 40, 56, 64, 80]))
+        K = int(rng.choice([1, 3, 8, 10, 25, 50, 70]))
     sigma = float(rng.choice([0.0, 1e-5, 1e-4, 1e-4, 3e-4, 1e-3]))
     clip_inside = bool(rng.random() < 0.8) if sigma > 0 else True
     scale = float(rng.choice([0.4, 0.6, 0.9]))
