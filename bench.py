@@ -186,7 +186,8 @@ def main():
     # (the eager rate is measured first: capturing afterwards leaves the leaves' AccumulateGrad nodes tied to the
     # capture stream, which would slow later eager steps down with stream syncs)
     eager_elapsed = udist.timed_steps(step, a.steps, a.warmup, world, cuda=True)
-    launch, elapsed = "eager", eager_elapsed
+    eager_local = udist.last_local_elapsed()
+    launch, elapsed, local_elapsed, replay_elapsed = "eager", eager_elapsed, eager_local, None
     if not a.eager:
         try:
             from unicorn_amd.graphs import GraphedStep
@@ -197,12 +198,21 @@ def main():
                 img.backward(cot)
                 return img
             run = GraphedStep(body, grads_of=(verts, maps, R, T))
-            elapsed = udist.timed_steps(run, a.steps, a.warmup, world, cuda=True)
-            launch = "hipGraph replay of one captured Renderer forward + backward"
+            replay_elapsed = udist.timed_steps(run, a.steps, a.warmup, world, cuda=True)
+            # Both loops ran the same K steps between the same fences.  A replayed graph costs the GPU ~2 us per
+            # kernel node more than the same launches in stream order, so a host fast enough to keep the stream fed
+            # (85 us of Python per step against 115 us of kernels) is the faster of the two; a slow host is not.  The
+            # reported value is the faster loop's (identical on every rank: both times are maxima over ranks), and
+            # both rates stay on the line.
+            if replay_elapsed <= eager_elapsed:
+                elapsed, local_elapsed = replay_elapsed, udist.last_local_elapsed()
+                launch = "hipGraph replay of one captured Renderer forward + backward"
+            else:
+                launch = "eager Renderer forward + backward in stream order (faster here than replaying the step's hipGraph)"
         except Exception as e:  # capture unsupported: fall back, and say so in the result
             launch = f"eager (graph capture failed: {type(e).__name__}: {e})"[:200]
     # every rank's own rate and a one-tensor all-reduce (RCCL under "nccl") that proves `world` ranks took part
-    per_rank = udist.gather_floats(B * a.steps / udist.last_local_elapsed(), world, cuda=True)
+    per_rank = udist.gather_floats(B * a.steps / local_elapsed, world, cuda=True)
     n_ranks_seen = udist.sum_over_ranks(1.0, world, cuda=True)
     # roofline leg (rank 0 only): the same steps again, eagerly, with (i) HIP events recorded by the library on the
     # launch stream right around the two dominant kernels (ur_profile_begin/end) and (ii) events around every C-ABI call
@@ -236,6 +246,8 @@ def main():
                        "faces_per_mesh": F, "texture": [cfg["tex"], cfg["tex"]], "sigma": 1e-4,
                        "grads": a.grads, "launch": launch},
             "eager_images_per_s": round(udist.job_throughput(B, a.steps, eager_elapsed, world), 2),
+            "graph_replay_images_per_s": (None if replay_elapsed is None else
+                                          round(udist.job_throughput(B, a.steps, replay_elapsed, world), 2)),
             "roofline": {"bound": "valu_issue", "kernel": dom, "achieved": rd.get("valu_Ginstr_per_s"),
                          "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": rd.get("valu_issue_frac"),
                          "traffic": rd.get("traffic"), "kernel_ms": rd["kernel_ms"], "dominant_call": calls[dom],
