@@ -181,8 +181,8 @@ def main():
         img.backward(cot)
         return img
 
-    # Eager steps cost 0.17-0.3 ms of Python / autograd on the host (box dependent) against ~0.165 ms of kernels, so
-    # the timed loop replays the step's hipGraph: the same kernels on the same buffers, one launch per step.
+    # Eager steps cost 0.08-0.15 ms of Python / autograd on the host (box dependent) against ~0.115 ms of kernels, so
+    # the step is also timed as a replay of its hipGraph: the same kernels on the same buffers, one launch per step.
     # (the eager rate is measured first: capturing afterwards leaves the leaves' AccumulateGrad nodes tied to the
     # capture stream, which would slow later eager steps down with stream syncs)
     eager_elapsed = udist.timed_steps(step, a.steps, a.warmup, world, cuda=True)
