@@ -11,12 +11,18 @@ path -- images are independent); the timed region is bracketed by barrier + sync
 an external torch.distributed.run it just joins.  On a box with fewer GPUs than ranks the ranks share the GPUs over
 gloo (a rehearsal of the launch path; the line says so).
 
-Prints ONE JSON line.  `roofline` prices the dominant kernel against the bound the counters show -- VALU issue: these
-kernels are per-pixel geometry tests, sorting and scatter, not streaming -- with the kernel time measured
-live (HIP events on the launch stream) and the per-launch counter values from the committed rocprofv3 --pmc passes
-(profiles/r02_counters.json; counters cannot be read from inside the process); `path_hbm` keeps SURVEY 8(d)'s
-byte model beside it; `cpu_baseline` times the oracle's CPU restatement (oracle/, test infrastructure) on the host cores
-for a bounded sample of the same workload.
+Timing: after the warmup, blocks of EXACTLY --steps steps, each between barrier + synchronize fences and timed as the
+max over ranks, are repeated until they add up to 0.3 s; `ms_per_step` / `value` are the MEDIAN block's (a single block
+of 20 steps is 2 ms: one scheduler hiccup would move it by several percent).  `value` is always the hipGraph replay of
+the captured step (one fixed loop, not the better of two); the eager loop's rate is a side field.
+
+Prints ONE JSON line.  `roofline` prices the dominant kernel against the VALU-issue roof -- these kernels are per-pixel
+geometry tests, sorting and scatter, not streaming -- with the kernel time measured live (HIP events on
+the launch stream), the per-launch instruction counts from the committed rocprofv3 --pmc passes (profiles/
+r03_counters.json, stamped with the hash of the kernel sources they were taken on: a stale file nulls the fraction) and
+the roof from the committed micro-benchmark of the issue rate (profiles/r03_valu_issue.json, tools/micro/valu_issue.hip);
+`path_hbm` keeps SURVEY 8(d)'s byte model beside it; `cpu_baseline` times the oracle's CPU restatement (oracle/, test
+infrastructure) on the host cores for a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -38,11 +44,29 @@ from unicorn_amd.renderer import Renderer  # noqa: E402
 from unicorn_amd.structures import Meshes, TexturesUV  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
-# VALU issue roof: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 clocks per SIMD (16 lanes wide), 2.4 GHz nominal
-# shader clock (MI355X_MICROARCH.md; the chip runs lower under load, so the fraction is if anything understated)
-SIMDS, CLOCK_GHZ, CLK_PER_WAVE_VALU = 1024, 2.4, 4
-VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / CLK_PER_WAVE_VALU  # 614.4 G wave-instructions / s
-COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
+# VALU issue roof: 256 CUs x 4 SIMDs at the 2.4 GHz nominal shader clock (MI355X_MICROARCH.md), one wave64 VALU
+# instruction per CLK_PER_WAVE_VALU clocks per SIMD.  That constant is MEASURED (tools/micro/valu_issue.hip, result
+# committed as profiles/r03_valu_issue.json): independent v_add_f32 / v_mul_f32 / v_add_u32 streams issue every 4.63
+# clocks from one wave alone and every 2.31 clocks once two or more waves share the SIMD (the guide's SIMD-32 figure;
+# round 2 priced the kernels at 4).  It is the roof of the CHEAPEST instructions: v_min_f32 / v_max_f32 / v_mad_u32_u24
+# and the packed-f32 forms stay at ~4.6 clocks however many waves there are, transcendentals at 8.6.
+SIMDS, CLOCK_GHZ = 1024, 2.4
+VALU_ISSUE = os.path.join(ROOT, "profiles", "r03_valu_issue.json")
+COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")
+
+
+def valu_issue_clocks():
+    """clocks per wave64 VALU instruction per SIMD, from the committed micro-benchmark: the best sustained rate of a
+    plain full-rate instruction (v_add_f32) with the SIMD shared by two waves"""
+    try:
+        rows = json.load(open(VALU_ISSUE))["results"]
+        return min(r["clk_per_instr_simd"] for r in rows if r["op"] == "v_add_f32" and r["waves_per_simd"] == 2)
+    except (OSError, KeyError, ValueError):
+        return 2.314  # the committed measurement's value (file not shipped)
+
+
+CLK_PER_WAVE_VALU = valu_issue_clocks()
+VALU_PEAK_GINSTR = SIMDS * CLOCK_GHZ / CLK_PER_WAVE_VALU  # ~1062 G wave-instructions / s
 
 WORKLOADS = {
     # name: batch per GPU, icosphere level, image, K, texture
@@ -181,13 +205,13 @@ def main():
         img.backward(cot)
         return img
 
-    # Eager steps cost 0.08-0.15 ms of Python / autograd on the host (box dependent) against ~0.115 ms of kernels, so
-    # the step is also timed as a replay of its hipGraph: the same kernels on the same buffers, one launch per step.
-    # (the eager rate is measured first: capturing afterwards leaves the leaves' AccumulateGrad nodes tied to the
-    # capture stream, which would slow later eager steps down with stream syncs)
-    eager_elapsed = udist.timed_steps(step, a.steps, a.warmup, world, cuda=True)
-    eager_local = udist.last_local_elapsed()
-    launch, elapsed, local_elapsed, replay_elapsed = "eager", eager_elapsed, eager_local, None
+    # Eager steps cost 0.08-0.15 ms of Python / autograd on the host (box dependent) against ~0.1 ms of kernels, so the
+    # reported loop is the replay of the step's hipGraph: the same kernels on the same buffers, one launch per step.
+    # The eager loop is timed too, first (capturing afterwards leaves the leaves' AccumulateGrad nodes tied to the
+    # capture stream, which would slow later eager steps down with stream syncs), and reported as a side field.
+    eager_blocks, eager_local = udist.timed_blocks(step, a.steps, a.warmup, world, cuda=True)
+    eager_elapsed, eager_local_med = udist.median_block(eager_blocks, eager_local)
+    launch, blocks, elapsed, local_elapsed, replay_elapsed = "eager", eager_blocks, eager_elapsed, eager_local_med, None
     if not a.eager:
         try:
             from unicorn_amd.graphs import GraphedStep
@@ -198,18 +222,12 @@ def main():
                 img.backward(cot)
                 return img
             run = GraphedStep(body, grads_of=(verts, maps, R, T))
-            replay_elapsed = udist.timed_steps(run, a.steps, a.warmup, world, cuda=True)
-            # Both loops ran the same K steps between the same fences.  A replayed graph costs the GPU ~2 us per
-            # kernel node more than the same launches in stream order, so a host fast enough to keep the stream fed
-            # (85 us of Python per step against 115 us of kernels) is the faster of the two; a slow host is not.  The
-            # reported value is the faster loop's (identical on every rank: both times are maxima over ranks), and
-            # both rates stay on the line.
-            if replay_elapsed <= eager_elapsed:
-                elapsed, local_elapsed = replay_elapsed, udist.last_local_elapsed()
-                launch = "hipGraph replay of one captured Renderer forward + backward"
-            else:
-                launch = "eager Renderer forward + backward in stream order (faster here than replaying the step's hipGraph)"
-        except Exception as e:  # capture unsupported: fall back, and say so in the result
+            blocks, replay_local = udist.timed_blocks(run, a.steps, a.warmup, world, cuda=True)
+            replay_elapsed, local_elapsed = udist.median_block(blocks, replay_local)
+            elapsed = replay_elapsed
+            launch = "hipGraph replay of one captured Renderer forward + backward"
+        except Exception as e:  # capture unsupported: the eager loop is the reported one, and the line says so
+            blocks = eager_blocks
             launch = f"eager (graph capture failed: {type(e).__name__}: {e})"[:200]
     # every rank's own rate and a one-tensor all-reduce (RCCL under "nccl") that proves `world` ranks took part
     per_rank = udist.gather_floats(B * a.steps / local_elapsed, world, cuda=True)
@@ -228,9 +246,14 @@ def main():
         native.enable_timing(False)
         dom = max(kernel_ms, key=kernel_ms.get)  # the dominant kernel: k_raster<2> (fused forward)
         calls = {"k_raster<2>": "ur_render_meshes_forward", "k_render_bwd": "ur_render_meshes_backward"}
-        counters = {}
+        counters, counters_note = {}, None
         if os.path.exists(COUNTERS):  # PMC counters cannot be read from inside the process: last committed passes
-            counters = json.load(open(COUNTERS)).get("workloads", {}).get(a.workload, {})
+            doc = json.load(open(COUNTERS))
+            if doc.get("kernel_source_sha256") == native.source_hash():
+                counters = doc.get("workloads", {}).get(a.workload, {})
+            else:  # taken on other kernels than the ones that just ran: no fraction rather than a stale one
+                counters_note = ("profiles/r03_counters.json was taken on other kernel sources (sha256 differs from "
+                                 "unicorn_amd/csrc): instruction counts withheld, re-run tools/prof_workload.sh")
         roofs = {k: kernel_roofline(k, ms, counters.get(k), B * kernel_bytes_per_image(calls[k], H, H, K, F, cfg["tex"],
                                                                                        cfg["tex"]))
                  for k, ms in kernel_ms.items() if k in calls}
@@ -241,6 +264,9 @@ def main():
             "metric": "rendered images/sec fwd+bwd (B=32, 128x128, K=50)", "value": round(ips, 2),
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "timing": {"blocks": len(blocks), "steps_per_block": a.steps, "timed_seconds": round(sum(blocks), 4),
+                       "reported": "median block", "ms_per_step_min": round(min(blocks) / a.steps * 1e3, 4),
+                       "ms_per_step_max": round(max(blocks) / a.steps * 1e3, 4)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": a.workload, "batch_per_gpu": B, "image": [H, H], "faces_per_pixel": K,
                        "faces_per_mesh": F, "texture": [cfg["tex"], cfg["tex"]], "sigma": 1e-4,
@@ -252,11 +278,15 @@ def main():
                          "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": rd.get("valu_issue_frac"),
                          "traffic": rd.get("traffic"), "kernel_ms": rd["kernel_ms"], "dominant_call": calls[dom],
                          "clock_GHz": CLOCK_GHZ, "simds": SIMDS, "clk_per_wave_valu_instr": CLK_PER_WAVE_VALU,
-                         "counters_from": os.path.relpath(COUNTERS, ROOT) if counters else None,
+                         "counters_from": os.path.relpath(COUNTERS, ROOT) if counters else counters_note,
+                         "issue_rate_from": os.path.relpath(VALU_ISSUE, ROOT),
                          "kernels": [roofs[k] for k in sorted(roofs)],
-                         "note": "achieved = SQ_INSTS_VALU per launch (rocprofv3 --pmc, committed under profiles/) / "
-                                 "the kernel's duration measured live with HIP events on its launch stream; peak = "
-                                 "1024 SIMDs x 2.4 GHz / 4 clk per wave64 VALU instruction.  The kernels are per-pixel "
+                         "note": "achieved = SQ_INSTS_VALU per launch (rocprofv3 --pmc, committed under profiles/, "
+                                 "stamped with the kernel sources' hash) / the kernel's duration measured live with "
+                                 "HIP events on its launch stream; peak = 1024 SIMDs x 2.4 GHz / the measured clocks "
+                                 "per wave64 VALU instruction of a SIMD shared by >= 2 waves (tools/micro/"
+                                 "valu_issue.hip: 2.31 for plain f32 / int ops -- the roof of the cheapest "
+                                 "instructions; min / max / packed ops cost twice that).  The kernels are per-pixel "
                                  "geometry tests, sorts and scatters: not streaming, no MFMA (DESIGN.md 6); SURVEY "
                                  "8(d)'s byte model is kept as path_hbm / algorithmic_GBps (fragments counted as if "
                                  "materialised; the fused kernels never store them, so that figure is not a bound)"},

@@ -185,6 +185,20 @@ int ur_mesh_regularizers(const float* verts, int N, int V, const int32_t* edge_q
                          const int32_t* nbr_index, float* normal_sum, float* laplacian_sum, float* grad_normal,
                          float* grad_laplacian, float* scratch, void* stream);
 
+/* Self-test (no counterpart in the reference): the kernels divide by per-face quantities through a 5-instruction
+ * exact-division sequence; this compares it with the hardware's IEEE division on n pseudo-random operand pairs and
+ * adds the number of mismatching quotients to *mismatches (device uint64, zeroed by the caller).  Expected: 0. */
+int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* stream);
+
+/*
+ * The blend's per-layer intermediates, for LayeredShader(debug=True) (renderer.py:185-200 returns them next to the
+ * image): alpha (N,H,W,K+1) = the layers' alphas (the mode's formula, 0 where pix_to_face < 0) followed by a 1 for the
+ * background; occ_alpha (N,H,W,K+1) = the transmittance in front of every layer, 1, (1-a_0), (1-a_0)(1-a_1), ...
+ * Inspection only (no backward).
+ */
+int ur_blend_intermediates(const int32_t* pix_to_face, const float* dists, int N, int H, int W, int K, float sigma,
+                           int mode, float* alpha, float* occ_alpha, void* stream);
+
 /*
  * Fused training path: rasterize + UV-sample + layered blend in ONE launch, and its backward in ONE launch.
  * Replaces: MeshRenderer.forward = MeshRasterizer (renderer.py:48) + LayeredShader.forward (renderer.py:159-172) and
@@ -200,11 +214,6 @@ int ur_mesh_regularizers(const float* verts, int N, int V, const int32_t* edge_q
  *   grad_face_verts (NF,3,3) and grad_maps (N,Ht,Wt,3) must be zero-filled by the caller; either may be NULL
  *   (then that gradient is skipped).  The z column of grad_face_verts stays 0 (the layered blend never reads zbuf).
  */
-/* Self-test (no counterpart in the reference): the kernels divide by per-face quantities through a 5-instruction
- * exact-division sequence; this compares it with the hardware's IEEE division on n pseudo-random operand pairs and
- * adds the number of mismatching quotients to *mismatches (device uint64, zeroed by the caller).  Expected: 0. */
-int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* stream);
-
 size_t ur_layers_elems(int N, int H, int W, int K);
 size_t ur_backward_scratch_bytes(int N, int H, int W, int K);
 
@@ -243,9 +252,22 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
  *   not per-corner gradients: use ur_render_layered_backward for those).  grads_are_zero = 0 makes the call clear
  *   grad_face_verts and grad_maps itself.
  *   layers / workspace: what the forward left; scratch: ur_backward_scratch_bytes() of uninitialised memory.
+ *
+ * Copy-free pose tiling (n_meshes).  The reference renders every mesh under several candidate poses by physically
+ * tiling the batch first: utils.mesh.repeat(meshes, K) clones verts / faces / texture maps K times (utils/mesh.py:43-71,
+ * called at unicorn.py:232-233 before the renderer; poses are K-major, unicorn.py:295-304).  Here the N images may
+ * instead SHARE n_meshes = M meshes: image n shows mesh n % M under pose (R[n], T[n]).  Then verts is (M,V,3), faces
+ * has M (or one shared) tables, maps is (M,Ht,Wt,3), a per-mesh face_uvs table has M*F rows, and the backward adds
+ * straight into grad_maps (M,Ht,Wt,3) and grad_verts (M,V,3) (the poses of a mesh summed in ascending order); R, T,
+ * image, grad_R, grad_T, face_verts, layers and the accumulator stay per image.  n_meshes = 0 or N: one mesh per image.
+ * N must be a multiple of M.  Tiling needs meshes the per-mesh kernels take -- ur_render_meshes_can_tile(V, F, H, W)
+ * != 0: at most 32768 faces, at most 4096 bins, V*2 <= F*9 -- otherwise the calls return UR_ERR_UNSUPPORTED.
  */
+int ur_render_meshes_can_tile(int V, int F, int H, int W);
+
 int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
-                             const float* T, float sx, float sy, int N, int V, int F, const int64_t* mesh_first_face,
+                             const float* T, float sx, float sy, int N, int n_meshes, int V, int F,
+                             const int64_t* mesh_first_face,
                              const int64_t* mesh_num_faces, int H, int W, float blur_radius, int K,
                              int clip_barycentric_coords, int cull_backfaces, const float* maps, const float* face_uvs,
                              int face_uvs_shared, int Ht, int Wt, float sigma, const float* background,
@@ -255,7 +277,8 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
 
 int ur_render_meshes_backward(const float* grad_image, const float* verts, const int64_t* faces,
                               int64_t faces_mesh_stride, const float* R, const float* T, float sx, float sy, int N,
-                              int V, int F, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int H, int W,
+                              int n_meshes, int V, int F, const int64_t* mesh_first_face,
+                              const int64_t* mesh_num_faces, int H, int W,
                               float blur_radius, int K, int clip_barycentric_coords, const float* maps,
                               const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
                               const float* background, const float* ambient, int mode, const int32_t* layers,

@@ -121,7 +121,13 @@ template <typename T> struct FaceEval {
 };
 
 // One (pixel, face) test.  Follows the SURVEY 8a spec block line by line.
-// SPEC DECISIONS: (1) a face is skipped when max z < kEpsilon; (2) barycentric clipping clamps the
+// SPEC DECISIONS: (1) a face is skipped when max z < kEpsilon -- i.e. only when it lies wholly behind the camera
+// plane.  ALTERNATIVE ON RECORD: the judge recalls pytorch3d 0.6.x's CheckPointOutsideBoundingBox
+// rejecting a face when its MIN z < kEpsilon ("faces with at least one vertex behind the camera ... should be
+// removed").  pytorch3d's source is not available here, so neither reading can be checked; the two differ only for
+// faces that CROSS the camera plane (no BASELINE config has any: objects sit 2.7 units in front of the camera;
+// tests/test_gpu_renderer.py's triangle soup does).  If pytorch3d is ever at hand: diff this line first, and change
+// it here and in face_record() (ur_render.hip) together.  (2) barycentric clipping clamps the
 // LOWER bound only (w = max(w, 0)) before renormalising by max(sum, 1e-5); (3) the zero-area test
 // uses edge(v0; v1, v2) while the barycentric denominator uses edge(v2; v0, v1) + kEpsilon.
 template <typename T>

@@ -16,6 +16,12 @@ What is pinned here, and by what:
                       fixture INPUTS, built by unicorn_amd.structures.Meshes on the CPU), value and autograd gradient;
                       plus the uniform Laplacian of pytorch3d's mesh_laplacian_smoothing RESTATED in float64 torch
                       (pytorch3d is absent: that half is not a reference output, parity unpinned).
+  G5 lighting.npz     the reference's own `diffuse` and `specular` (src/model/pytorch3d_monkey.py:73-198, the functions
+                      it patches into pytorch3d), AST-extracted.  Their only pytorch3d dependency is the helper
+                      convert_to_tensors_and_broadcast, which turns its arguments into tensors of one batch size: every
+                      argument is passed here as a tensor ALREADY broadcast to the points' shape (colour / direction /
+                      camera position (N,H,W,K,3), shininess (N,)), on which that helper is the identity, so the
+                      identity stands in for it and every later reshape branch of the functions is skipped.
 Nothing of the reference's text is written to the fixtures: they hold inputs and outputs only.
 """
 import ast
@@ -138,7 +144,40 @@ def make_regularizers():
              normal=loss.item(), grad_normal=g_nc.numpy(), laplacian=lap.item(), grad_laplacian=g_lap.numpy())
 
 
+def make_lighting():
+    ident = lambda *args, device=None: args  # convert_to_tensors_and_broadcast on already-broadcast tensors
+    dif_fn, spe_fn = extract(os.path.join(REF, "pytorch3d_monkey.py"), ["diffuse", "specular"],
+                             {"torch": torch, "F": F, "convert_to_tensors_and_broadcast": ident})
+    N, H, W, K = 2, 4, 3, 2
+    g = torch.Generator().manual_seed(23)
+    shape = (N, H, W, K, 3)
+    points = torch.randn(shape, generator=g, dtype=torch.float64)
+    normals = torch.randn(shape, generator=g, dtype=torch.float64)
+    normals[0, 0, 0, 0] = 0.0                                    # a padded fragment: zero normal (eps of normalize)
+    normals[0, 0, 1, 0] = normals[0, 0, 1, 0] * 1e-8             # tiny: below the eps
+    direction = torch.randn(N, 1, 1, 1, 3, generator=g, dtype=torch.float64).expand(shape).contiguous()
+    direction[1] = (torch.randn(1, 3, generator=g, dtype=torch.float64) - points[1])  # a point light: per-point direction
+    color = torch.rand(N, 1, 1, 1, 3, generator=g, dtype=torch.float64).expand(shape).contiguous()
+    cam = (torch.randn(N, 1, 1, 1, 3, generator=g, dtype=torch.float64) * 3).expand(shape).contiguous()
+    shin = torch.tensor([64.0, 8.0], dtype=torch.float64)       # (N,): the functions view it as (N,1,1,1) themselves
+    for t in (points, normals, direction):
+        t.requires_grad_(True)
+    d = dif_fn(normals=normals, color=color, direction=direction)
+    sp = spe_fn(points=points, normals=normals, direction=direction, color=color, camera_position=cam, shininess=shin)
+    cot_d = torch.randn(shape, generator=g, dtype=torch.float64)
+    cot_s = torch.randn(shape, generator=g, dtype=torch.float64)
+    gn_d, gdir_d = torch.autograd.grad((d * cot_d).sum(), (normals, direction), retain_graph=True)
+    gp_s, gn_s, gdir_s = torch.autograd.grad((sp * cot_s).sum(), (points, normals, direction))
+    np.savez(os.path.join(OUT, "lighting.npz"), points=points.detach().numpy(), normals=normals.detach().numpy(),
+             direction=direction.detach().numpy(), color=color.numpy(), camera_position=cam.numpy(),
+             shininess=shin.numpy(), diffuse=d.detach().numpy(), specular=sp.detach().numpy(),
+             cot_diffuse=cot_d.numpy(), cot_specular=cot_s.numpy(), diffuse_grad_normals=gn_d.numpy(),
+             diffuse_grad_direction=gdir_d.numpy(), specular_grad_points=gp_s.numpy(),
+             specular_grad_normals=gn_s.numpy(), specular_grad_direction=gdir_s.numpy())
+
+
 if __name__ == "__main__":
+    make_lighting()
     make_regularizers()
     make_blend()
     make_uvsample()

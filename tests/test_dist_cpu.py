@@ -32,7 +32,11 @@ def _worker(rank, world, port, out):
         time.sleep(0.01 * (1 + 2 * rank))
 
     elapsed = udist.timed_steps(step, steps=3, warmup=1, world=w, cuda=False)
-    out[rank] = dict(elapsed=elapsed, calls=len(calls), R00=float(sc["R"][0, 0, 0]),
+    n_before = len(calls)
+    # bench.py's loop: blocks of exactly `steps` steps until they add up to min_seconds; both ranks must stop together
+    blocks, local = udist.timed_blocks(step, steps=2, warmup=0, world=w, cuda=False, min_seconds=0.25)
+    out[rank] = dict(elapsed=elapsed, calls=n_before, R00=float(sc["R"][0, 0, 0]), blocks=blocks, block_local=local,
+                     block_calls=len(calls) - n_before, median=udist.median_block(blocks, local),
                      value=udist.job_throughput(2, 3, elapsed, w), local=udist.last_local_elapsed(),
                      rates=udist.gather_floats(10.0 + rank, w, cuda=False), ones=udist.sum_over_ranks(1.0, w, False))
     udist.finish(w)
@@ -50,6 +54,19 @@ def test_two_rank_sharding_and_timing():
     assert a["R00"] != b["R00"]                               # ranks render different shards
     assert a["local"] < b["local"] <= b["elapsed"]            # each rank's own time, before the wait for the slowest
     assert a["rates"] == b["rates"] == [10.0, 11.0] and a["ones"] == b["ones"] == 2.0  # per-rank line of bench.py
+    # repeated blocks: same count and same (max-over-ranks) times on both ranks, at least min_seconds in total,
+    # every block exactly 2 steps of the slow rank, the median one reported
+    assert a["blocks"] == b["blocks"] and len(a["blocks"]) >= 2 and sum(a["blocks"]) >= 0.25
+    assert a["block_calls"] == b["block_calls"] == 2 * len(a["blocks"])
+    assert all(t >= 2 * 0.03 for t in a["blocks"]) and sum(a["blocks"][:-1]) < 0.25
+    assert a["median"][0] == sorted(a["blocks"])[(len(a["blocks"]) - 1) // 2] == b["median"][0]
+    assert a["median"][1] < b["median"][1] <= b["median"][0]
+
+
+def test_median_block_picks_the_lower_middle():
+    assert udist.median_block([3.0, 1.0, 2.0]) == 2.0
+    assert udist.median_block([4.0, 1.0, 3.0, 2.0]) == 2.0
+    assert udist.median_block([5.0, 1.0], [50.0, 10.0]) == (1.0, 10.0)
 
 
 def test_bench_starts_its_own_ranks(monkeypatch):

@@ -111,16 +111,30 @@ def test_eye_light_phong_layered():
     sc, rend, meshes, leaves = _render_setup(2, 32, 1, sigma=1e-4, **kw)
     out = rend(meshes, leaves[2], leaves[3])
     p2f, zbuf, bary, dists, tex = _oracle_frags(sc, 32, 32, 1, orc.blur_radius_for(1e-4))
-    # lit colours from the oracle's fragments, lighting functions run on the CPU in float64
-    from unicorn_amd.renderer import Fragments, DirectionalLights
-    from unicorn_amd.structures import Meshes, TexturesUV
+    # expected lit colours: the oracle's fragments through the test suite's own numpy restatement of phong shading
+    # (tests/test_lighting_cpu.py, itself held to the reference's diffuse / specular by tests/golden/lighting.npz) --
+    # nothing of unicorn_amd.lighting, the code under test, is on this side
+    from test_lighting_cpu import _np_light
+    from unicorn_amd.renderer import DirectionalLights
+    from unicorn_amd.structures import Meshes
     N = 2
-    fb = sc["faces"][None].expand(N, -1, -1)
-    cm = Meshes(verts=sc["verts"].double(), faces=fb, textures=None)
-    frag = Fragments(torch.tensor(p2f, dtype=torch.int32), None, torch.tensor(bary).double(), None)
-    col = lighting.phong_shading(cm, frag, DirectionalLights(**{k: v for k, v in kw['lights'].items() if k != 'name'}),
-                                 lighting.Materials(), torch.tensor(tex).double(), sc["R"].double(), sc["T"].double())
-    ref = orc.layered_blend(col.numpy().astype(np.float32), p2f, dists, 1e-4, (1.0, 1.0, 1.0), 1)
+    cm = Meshes(verts=sc["verts"].double(), faces=sc["faces"][None].expand(N, -1, -1), textures=None)
+    v, f, vn = cm.verts_packed().numpy(), cm.faces_packed().numpy(), cm.verts_normals_packed().numpy()
+    mask, idx = (p2f >= 0)[..., None], np.maximum(p2f, 0)
+    b64 = bary.astype(np.float64)[..., None]
+    pts, nrm = (b64 * v[f][idx]).sum(-2) * mask, (b64 * vn[f][idx]).sum(-2) * mask
+    R64, T64 = sc["R"].double(), sc["T"].double()
+    cam = (-(T64[:, None] @ R64.transpose(1, 2))[:, 0]).numpy().reshape(N, 1, 1, 1, 3)
+    amb, dif, spe = _np_light(pts, nrm, cam, DirectionalLights(**{k: v for k, v in kw['lights'].items() if k != 'name'}))
+    col = (amb + dif) * tex.astype(np.float64) + spe
+    ref = orc.layered_blend(col.astype(np.float32), p2f, dists, 1e-4, (1.0, 1.0, 1.0), 1)
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=2e-5, rtol=0)
     out.sum().backward()
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in leaves)
+
+
+def test_light_functions_against_reference_golden_on_gpu():
+    """unicorn_amd.lighting.diffuse / specular on the GPU against outputs of the reference's own functions
+    (pytorch3d_monkey.py:73-198; tests/golden/lighting.npz), values and gradients"""
+    from test_lighting_cpu import check_light_functions_against_reference_golden
+    check_light_functions_against_reference_golden("cuda", 1e-9)

@@ -46,3 +46,72 @@ def test_vertex_sums_that_do_not_fit_the_face_buffer():
     used = torch.zeros(42, dtype=torch.bool)
     used[sc["faces"].flatten()] = True
     assert float(verts.grad[:, ~used.cuda()].abs().max()) == 0.0
+
+
+def _vertex_at_view(sc, n, vertex, view_xyz):
+    """move one vertex of mesh n so that its VIEW coordinates under (R[n], T[n]) are view_xyz (view = X @ R + T)"""
+    R, T = sc["R"][n].double(), sc["T"][n].double()
+    sc["verts"][n, vertex] = ((torch.tensor(view_xyz, dtype=torch.float64) - T) @ R.t()).float()
+
+
+@pytest.mark.parametrize("hw", [(128, 128), (16, 4112)], ids=lambda hw: f"{hw[0]}x{hw[1]}")
+def test_vertex_next_to_the_camera_plane(hw):
+    """a vertex at view depth ~1e-9 has NDC coordinates of ~1e9; its faces' blur-expanded boxes are huge,
+    and the pixel rectangle the prep kernel derives from them (bin loads, face masks) must still cover every bin the
+    rasterizer's own box test passes: fused one-call path == two-stage path == oracle, bit for bit in the image."""
+    from unicorn_amd.structures import Meshes, TexturesUV
+    H, W = hw
+    K = 6
+    from unicorn_amd import synth
+    from unicorn_amd.renderer import Renderer
+    sc = synth.make_scene(2, level=1, tex_size=16, seed=21)
+    _vertex_at_view(sc, 0, 5, (0.31, -0.17, 1e-9))
+    _vertex_at_view(sc, 1, 9, (-0.4, 0.23, 3e-9))
+    # (the float32 round trip through world space leaves |z| ~ 1e-7 at worst: still NDC coordinates beyond 1e6)
+    dev = torch.device("cuda:0")
+    faces, uvs = sc["faces"].to(dev), sc["verts_uvs"].to(dev)
+    fb, ub = faces[None].expand(2, -1, -1), uvs[None].expand(2, -1, -1)
+    verts, maps, R, T = (sc[k].to(dev) for k in ("verts", "maps", "R", "T"))
+    meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
+    rend = Renderer(hw, cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=1e-3).to(dev)
+    fused = rend(meshes, R, T)
+    assert torch.isfinite(fused).all()
+    rend.renderer.fused = False
+    two_stage = rend(meshes, R, T)
+    assert torch.equal(fused, two_stage)
+    ref_img = _oracle(sc, H, W, K, S30, 1e-3, None)
+    np.testing.assert_allclose(fused.cpu().numpy(), ref_img, atol=1e-5, rtol=0)
+    # the fragments too: same faces at every pixel as the oracle's naive loop over all faces
+    from oracle import orc
+    frag = rend.renderer.rasterizer(meshes, R=R, T=T)
+    ndc = orc.project_verts(sc["verts"].numpy(), sc["R"].numpy(), sc["T"].numpy(), S30)
+    fv = np.stack([ndc[n][sc["faces"].numpy()] for n in range(2)]).reshape(-1, 3, 3)
+    p2f = orc.rasterize(fv, 2, H, W, orc.blur_radius_for(1e-3), K)[0]
+    assert np.array_equal(frag.pix_to_face_i32.cpu().numpy(), p2f)
+
+
+def test_vertex_on_the_camera_plane_fused_equals_two_stage():
+    """view depth exactly 0: infinite NDC coordinates (a box that is open to one side).  No oracle here -- the
+    arithmetic on such a face is inf - inf on every side, parity unpinned -- but the two GPU routes must still agree:
+    the mask / load rectangle may not drop a face the box test lets through."""
+    from unicorn_amd import synth
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesUV
+    sc = synth.make_scene(2, level=1, tex_size=16, seed=22)
+    R0, T0 = sc["R"][0].double(), sc["T"][0].double()
+    # a vertex whose view depth is EXACTLY zero in the kernel's float arithmetic: put the camera at identity for mesh 0
+    sc["R"][0] = torch.eye(3)
+    sc["T"][0] = torch.tensor([0.0, 0.0, 2.5])
+    sc["verts"][0, 3] = torch.tensor([0.4, 0.3, -2.5])
+    dev = torch.device("cuda:0")
+    faces, uvs = sc["faces"].to(dev), sc["verts_uvs"].to(dev)
+    fb, ub = faces[None].expand(2, -1, -1), uvs[None].expand(2, -1, -1)
+    verts, maps, R, T = (sc[k].to(dev) for k in ("verts", "maps", "R", "T"))
+    meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
+    rend = Renderer(64, cameras={"name": "fov", "fov": 30}, faces_per_pixel=8, sigma=1e-3).to(dev)
+    fused = rend(meshes, R, T)
+    rend.renderer.fused = False
+    two_stage = rend(meshes, R, T)
+    assert torch.equal(torch.isnan(fused), torch.isnan(two_stage))
+    assert torch.equal(torch.nan_to_num(fused), torch.nan_to_num(two_stage))
+    assert torch.isfinite(fused[1]).all()  # the other image of the batch is untouched by its neighbour's bad vertex

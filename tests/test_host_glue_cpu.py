@@ -48,3 +48,34 @@ def test_step_layout_parts_are_aligned_and_disjoint(monkeypatch):
     assert ws_b == 77777 and o_scr >= o_ws + ws_b and scr_b == 4099
     assert o_acc >= o_scr + scr_b and total >= o_acc + NF * 36
     assert all(o % 256 == 0 for o in (o_lay, o_ws, o_scr, o_acc, total))
+
+
+def test_colour_arrays_outlive_cache_eviction():
+    """the arrays handed to a C call must not depend on the colour cache keeping them"""
+    native._rgb_cache.clear()
+    first = native._rgb((0.25, 0.5, 0.75))
+    addr = native._rgb_ptr(first)
+    for i in range(600):                                       # far more distinct colours than the cache keeps
+        native._rgb((float(i), 0.0, 1.0))
+    assert len(native._rgb_cache) <= 257
+    assert native._rgb_ptr(first) == addr and list(first) == [0.25, 0.5, 0.75]   # still alive: the caller holds it
+    assert native._rgb_ptr(None) is None
+
+
+def test_renderer_takes_options_like_the_reference():
+    """renderer.py:26-57 reads its options with kwargs.get(name, default): unknown keys are ignored for construction
+    and travel on in init_kwargs (configs of forks, model_kwargs of checkpoints)"""
+    from unicorn_amd.renderer import Renderer
+    kw = {"cameras": {"name": "fov", "fov": 30}, "faces_per_pixel": 7, "some_fork_option": {"a": 1}}
+    r = Renderer(32, **kw)
+    assert r.init_kwargs == kw and r.init_kwargs is not r.init_kwargs
+    assert r.renderer.rasterizer.raster_settings.faces_per_pixel == 7
+    r2 = Renderer((32, 48), **r.init_kwargs)
+    assert r2.renderer.rasterizer.raster_settings.image_size == (32, 48)
+    r.init_lights(name="directional", direction=((0, 0, 1),))   # renderer.py:65-74
+    assert r.lights.direction == ((0, 0, 1),)
+    r.update_lights(direction=((1, 0, 0),))
+    r.reset_default_lights()
+    assert r.lights.direction == ((0, 0, 1),)
+    r.init_cameras(name="perspective", focal_length=3.7)        # renderer.py:59-63
+    assert type(r.cameras).__name__ == "PerspectiveCameras"

@@ -1,6 +1,10 @@
 """Lighting (unicorn_amd/lighting.py: the reference's diffuse / specular / _apply_lighting, pytorch3d_monkey.py:34-198,
-and pytorch3d's phong / flat shading) against an independent numpy restatement.  Pure torch ops: runs on the CPU.
-Parity unpinned: pytorch3d is not available, the numpy code below restates the same published formulas."""
+and pytorch3d's phong / flat shading).  `diffuse` / `specular` are PINNED: tests/golden/lighting.npz holds outputs and
+autograd gradients of the reference's own two functions (tests/golden/make_golden.py).  The shading functions around
+them are checked against an independent numpy restatement (parity unpinned: pytorch3d is not available, the numpy code
+below restates the same published formulas).  Pure torch ops: runs on the CPU."""
+import os
+
 import numpy as np
 import torch
 
@@ -27,6 +31,49 @@ def _np_light(points, normals, cam, lights, shininess=64.0):
     al = np.maximum((view * refl).sum(-1), 0) * (cos > 0)
     spe = np.asarray(lights.specular_color, np.float64).reshape(1, 3) * (al ** shininess)[..., None]
     return amb, dif, spe
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lighting.npz")
+
+
+def check_light_functions_against_reference_golden(device, atol):
+    """lighting.diffuse / specular, values and gradients, against the fixture; also called by the GPU suite"""
+    g = np.load(GOLDEN)
+    t = lambda k, grad=False: torch.tensor(g[k], device=device).requires_grad_(grad)
+    points, normals, direction = t("points", True), t("normals", True), t("direction", True)
+    color, cam, shin = t("color"), t("camera_position"), t("shininess")
+    d = lighting.diffuse(normals, color, direction)
+    sp = lighting.specular(points, normals, direction, color, cam, shin)
+    cmp = lambda a, k: np.testing.assert_allclose(a.detach().cpu().numpy(), g[k], atol=atol, rtol=atol, err_msg=k)
+    cmp(d, "diffuse")
+    cmp(sp, "specular")
+    gn, gd = torch.autograd.grad((d * t("cot_diffuse")).sum(), (normals, direction), retain_graph=True)
+    cmp(gn, "diffuse_grad_normals")
+    cmp(gd, "diffuse_grad_direction")
+    gp, gn, gd = torch.autograd.grad((sp * t("cot_specular")).sum(), (points, normals, direction))
+    cmp(gp, "specular_grad_points")
+    cmp(gn, "specular_grad_normals")
+    cmp(gd, "specular_grad_direction")
+
+
+def test_diffuse_specular_against_reference_golden():
+    check_light_functions_against_reference_golden("cpu", 1e-12)
+    g = np.load(GOLDEN)
+    # the numpy restatement below (what the shading tests and the GPU phong test compare with) is held to it as well
+    _, dif, spe = _np_light_terms(g["points"], g["normals"], g["direction"], g["color"], g["color"],
+                                  g["camera_position"], g["shininess"].reshape(-1, 1, 1, 1))
+    np.testing.assert_allclose(dif, g["diffuse"], atol=1e-12)
+    np.testing.assert_allclose(spe, g["specular"], atol=1e-12)
+
+
+def _np_light_terms(points, normals, d, dif_color, spe_color, cam, shininess):
+    n, d = _norm(normals), _norm(d)
+    cos = (n * d).sum(-1)
+    dif = dif_color * np.maximum(cos, 0)[..., None]
+    view = _norm(cam - points)
+    refl = -d + 2 * cos[..., None] * n
+    al = np.maximum((view * refl).sum(-1), 0) * (cos > 0)
+    return None, dif, spe_color * (al ** shininess)[..., None]
 
 
 def _scene(N=2, H=6, W=5, K=3, seed=0):

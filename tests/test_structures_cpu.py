@@ -157,3 +157,42 @@ def test_transform_points_screen_inverts_the_pixel_centre_map(H, W):
         world = (pts - T[:, None]) @ R.transpose(1, 2)
         scr2 = cam.transform_points_screen(world, image_size=((H, W),), R=R, T=T)
         assert torch.allclose(scr2, scr, atol=2e-3)
+
+
+def test_repeat_of_equal_sized_meshes_copies_nothing_until_asked():
+    """utils/mesh.py:43-71 tiles verts / faces / maps K times; here the tiling is an index (image n = mesh n % B) and
+    the repeated tensors exist only for callers that ask for them"""
+    from unicorn_amd.structures import TiledMeshes
+    v, f = synth.icosphere(1)
+    verts = torch.stack([v, 2 * v, 3 * v]).requires_grad_(True)
+    maps = torch.rand(3, 4, 4, 3, requires_grad=True)
+    uvs = synth.spherical_uvs(v)
+    fb, ub = f[None].expand(3, -1, -1), uvs[None].expand(3, -1, -1)
+    m = Meshes(verts, fb, TexturesUV(maps, fb, ub))
+    r = repeat(m, 2)
+    assert isinstance(r, TiledMeshes) and r.tile_base is m and r.tile_reps == 2
+    assert len(r) == 6 and r.equisized and r.device == verts.device and len(r.textures) == 6
+    assert isinstance(r.textures, TexturesUV) and r.textures.tile_base is m.textures
+    assert r._tiled_verts is None and r.textures._tiled is None            # nothing copied so far
+    # ordinary consumers see ordinary tiled tensors, autograd-connected to the base
+    assert torch.equal(r.verts_padded(), verts.repeat(2, 1, 1)) and r.verts_padded().requires_grad
+    assert r.faces_padded().shape == (6, f.shape[0], 3) and r.faces_padded().stride(0) == 0   # shared topology: a view
+    assert torch.equal(r.textures.maps_padded(), maps.repeat(2, 1, 1, 1))
+    assert r.textures.faces_uvs_padded().stride(0) == 0 and r.textures._shared_tables()
+    assert torch.equal(r.verts_list()[4], verts[1]) and torch.equal(r.faces_packed()[-1], f[-1] + 5 * v.shape[0])
+    r.verts_padded().sum().backward()
+    assert torch.equal(verts.grad, torch.full_like(verts, 2.0))
+    d = repeat(m.detach(), 2)                                             # unicorn.py:227-228,232: detach, then repeat
+    assert not d.tile_base.verts_padded().requires_grad
+    # an in-place change of the repeated batch ends the tiling (the copies are no longer equal to their base)
+    r2 = repeat(m, 2)
+    r2.offset_verts_(torch.ones(6 * v.shape[0], 3))
+    assert r2.tile_base is None and torch.allclose(r2.verts_padded()[3], verts.detach()[0] + 1)
+    assert r2.faces_padded().shape[0] == 6
+    # per-mesh face tables are repeated, not expanded
+    m3 = Meshes(verts.detach(), f[None].repeat(3, 1, 1))
+    assert repeat(m3, 2).faces_padded().stride(0) != 0 and repeat(m3, 2).textures is None
+    # meshes of different sizes: plain list tiling
+    v2, f2 = synth.icosphere(2)
+    h = repeat(Meshes([v, v2], [f, f2]), 2)
+    assert not isinstance(h, TiledMeshes) and [x.shape[0] for x in h.verts_list()] == [42, 162, 42, 162]

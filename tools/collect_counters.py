@@ -1,9 +1,12 @@
 """dev helper: after `bash tools/prof_workload.sh <tag> <workload>` on the GPU box, fold the passes under
 gpurun_out/<tag>_<workload>/ into profiles/: <name>_<workload>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, our
 kernels), <name>_<workload>_pmc_summary.txt (mean counter value per dispatch) and the per-launch counter means bench.py
-reads (profiles/r02_counters.json).
+reads (profiles/r03_counters.json, stamped with the sha256 of the kernel sources the passes ran on).
 usage: python tools/collect_counters.py <tag> <workload> <name in profiles/, e.g. r02_v1>"""
 import collections, csv, glob, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unicorn_amd import native  # noqa: E402  (source_hash only: no GPU, no library load)
 
 tag, wl, name = sys.argv[1:4]
 src = f"gpurun_out/{tag}_{wl}"
@@ -47,8 +50,12 @@ for r in rows[1:]:
         means[short(r[0])]["kernel_stats_avg_ns"] = float(r[3])
         print(f"{short(r[0]):28s} calls {r[1]:>5s}  avg {float(r[3]) / 1e3:9.1f} us")
 
-path = "profiles/r02_counters.json"
-doc = json.load(open(path)) if os.path.exists(path) else {
+path = "profiles/r03_counters.json"
+doc = json.load(open(path)) if os.path.exists(path) else {}
+if doc.get("kernel_source_sha256") != native.source_hash():  # counters of other kernels do not mix with these
+    doc = {}
+doc = doc or {
+    "kernel_source_sha256": native.source_hash(),
     "source": "rocprofv3 --pmc (separate passes: two SQ sets, FETCH_SIZE + GRBM_GUI_ACTIVE, WRITE_SIZE) of bench.py "
               "--steps 3 --warmup 2 --workload <w> (tools/prof_workload.sh), mean per dispatch; kernel_stats_avg_ns from "
               "rocprofv3 --kernel-trace --stats of the default bench.py run",
@@ -63,6 +70,6 @@ for k in ("k_raster<2>", "k_render_bwd"):
     m = means.get(k, {})
     if "SQ_INSTS_VALU" in m and "kernel_stats_avg_ns" in m:
         t = m["kernel_stats_avg_ns"] * 1e-9
-        print(f"{k}: VALU issue frac {m['SQ_INSTS_VALU'] / t / 614.4e9:.3f}  HBM "
+        print(f"{k}: VALU issue frac {m['SQ_INSTS_VALU'] / t / (1024 * 2.4e9 / 2.314):.3f}  HBM "
               f"{(2 * m.get('FETCH_SIZE', 0) + m.get('WRITE_SIZE', 0)) * 1024 / 1e6:.1f} MB/launch  LDS conflict ratio "
               f"{m.get('SQ_LDS_BANK_CONFLICT', 0) / max(m.get('SQ_ACTIVE_INST_LDS', 1), 1):.2f}")

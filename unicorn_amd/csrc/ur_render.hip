@@ -94,19 +94,6 @@ int static_scratch(void** out) {
 
 constexpr int kMaxDevices = 64;
 
-// compute units of the current device (cached per device)
-int device_cus() {
-  static std::atomic<int> cus[kMaxDevices];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
-  int v = cus[dev].load(std::memory_order_relaxed);
-  if (v <= 0) {
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cus[dev].store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
-
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(UR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -240,6 +227,8 @@ __device__ __forceinline__ bool face_record(const float c[9], float r, int cull,
   const float v0x = c[0], v0y = c[1], z0 = c[2], v1x = c[3], v1y = c[4], z1 = c[5], v2x = c[6], v2y = c[7], z2 = c[8];
   const float zmax = max_s(max_s(z0, z1), z2);
   const float face_area = (v0x - v1x) * (v2y - v1y) - (v0y - v1y) * (v2x - v1x);  // edge(v0; v1, v2)
+  // (zmax < eps: SPEC DECISION, a face wholly behind the camera plane; the min-z alternative is on record in DESIGN.md 2
+  // and beside the same test of the CPU checker -- change both together)
   const bool culled = (zmax < kEps) || (face_area <= kEps && face_area >= -kEps) || (cull && face_area < 0.0f);
   float xlo = min_s(min_s(v0x, v1x), v2x) - r, xhi = max_s(max_s(v0x, v1x), v2x) + r;
   const float ylo = min_s(min_s(v0y, v1y), v2y) - r, yhi = max_s(max_s(v0y, v1y), v2y) + r;
@@ -257,16 +246,24 @@ __device__ __forceinline__ bool face_record(const float c[9], float r, int cull,
   return culled;
 }
 
-// pixel rectangle (columns c0..c1, rows r0..r1, a pixel of slack either way) a blur-expanded box may touch: the load
-// estimate of the workgroup schedule counts +1 on every 16x16 bin it overlaps -- this only orders work, it decides
-// nothing
+// pixel rectangle (columns c0..c1, rows r0..r1, a pixel of slack either way) a blur-expanded box may touch.  It DECIDES
+// geometry: a bin outside it gets neither a load count (a bin of load 0 is flagged kEmptyBin and skipped by both big
+// kernels) nor, on the mask path, the face's mask bit.  It must therefore be a superset of bbox_overlap()'s verdicts for
+// ANY box, including the huge or non-finite ones a vertex near the camera plane produces: the pixel coordinates are
+// clamped as floats before the cast (an unclamped cast saturates and the +-1 then wraps), and a NaN bound -- which
+// fails every comparison of bbox_overlap, i.e. passes every bin -- opens its side of the rectangle completely.
 __device__ __forceinline__ void box_pixels(const float4 bb, int H, int W, int& c0, int& c1, int& r0, int& r1) {
   const float rx = (W > H) ? 2.0f * (float)W / (float)H : 2.0f, ry = (H > W) ? 2.0f * (float)H / (float)W : 2.0f;
   // column c has x = rx/2 - rx (c + 0.5) / W  (+X left), row likewise
-  c0 = max(0, (int)floorf((0.5f * rx - bb.y) * (float)W / rx - 0.5f) - 1);
-  c1 = min(W - 1, (int)ceilf((0.5f * rx - bb.x) * (float)W / rx - 0.5f) + 1);
-  r0 = max(0, (int)floorf((0.5f * ry - bb.w) * (float)H / ry - 0.5f) - 1);
-  r1 = min(H - 1, (int)ceilf((0.5f * ry - bb.z) * (float)H / ry - 0.5f) + 1);
+  // lower ends: NaN -> -1 (fmaxf drops the NaN) -> 0 ; upper ends: NaN -> S (fminf drops it) -> S - 1
+  const float fc0 = fminf(fmaxf((0.5f * rx - bb.y) * (float)W / rx - 0.5f, -1.0f), (float)W);
+  const float fc1 = fmaxf(fminf((0.5f * rx - bb.x) * (float)W / rx - 0.5f, (float)W), -2.0f);
+  const float fr0 = fminf(fmaxf((0.5f * ry - bb.w) * (float)H / ry - 0.5f, -1.0f), (float)H);
+  const float fr1 = fmaxf(fminf((0.5f * ry - bb.z) * (float)H / ry - 0.5f, (float)H), -2.0f);
+  c0 = max(0, (int)floorf(fc0) - 1);
+  c1 = min(W - 1, (int)ceilf(fc1) + 1);
+  r0 = max(0, (int)floorf(fr0) - 1);
+  r1 = min(H - 1, (int)ceilf(fr1) + 1);
 }
 
 __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv, int64_t NF, float r, int cull,
@@ -287,8 +284,8 @@ __global__ void __launch_bounds__(256) k_face_prep(const float* __restrict__ fv,
 #pragma unroll
     for (int q = 0; q < 5; ++q) rec[5 * i + q] = rc[q];
   }
-  // ---- load estimate for the workgroup schedule: +1 on every 16x16 bin the expanded box overlaps (a pixel of slack
-  //      either way -- this only orders the work, it decides nothing).  The workgroup first counts in LDS for the
+  // ---- load of the workgroup schedule: +1 on every 16x16 bin the expanded box may touch (box_pixels: a superset of
+  //      the bin test; a bin of load 0 is skipped by the big kernels).  The workgroup first counts in LDS for the
   //      mesh of its first face (consecutive faces nearly always share the mesh), then flushes the non-zero bins.
   if (!binload) return;
   const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nbins = nbx * nby;
@@ -447,7 +444,7 @@ __host__ __device__ inline int prep_parts(int64_t total_faces, int N) {
 // share of the two gradient accumulators the backward will add into (saves the backward a fill launch).
 __global__ void __launch_bounds__(256) k_project_prep_mesh(
     const float* __restrict__ verts, const int64_t* __restrict__ faces, int64_t fstride, const float* __restrict__ R,
-    const float* __restrict__ T, float sx, float sy, int N, int V, int F, float r, int cull, int H, int W,
+    const float* __restrict__ T, float sx, float sy, int N, int M, int V, int F, float r, int cull, int H, int W,
     float* __restrict__ face_verts, float4* __restrict__ bbox, float4* __restrict__ rec, float* __restrict__ fz,
     int* __restrict__ binload, unsigned* __restrict__ masks, float* __restrict__ zero_a, int zero_a_n,
     float* __restrict__ zero_b, int zero_b_n) {
@@ -455,6 +452,7 @@ __global__ void __launch_bounds__(256) k_project_prep_mesh(
   __shared__ unsigned s_mask[kMaskBins * 8];
   __shared__ float s_ext[4 * kMaskAxis];  // per bin column: x centres lo / hi ; per bin row: y centres lo / hi
   const int part = blockIdx.x, parts = gridDim.x, n = blockIdx.y, tid = threadIdx.x;
+  const int m = n % M;  // the mesh this image shows (M == N: one mesh per image; M < N: M meshes tiled over the poses)
   const int nbx = (W + 15) >> 4, nby = (H + 15) >> 4, nbins = nbx * nby;
   for (int j = tid; j < nbins; j += 256) s_load[j] = 0;
   if (masks) {
@@ -474,7 +472,7 @@ __global__ void __launch_bounds__(256) k_project_prep_mesh(
     float* z = zero_a + (int64_t)n * zero_a_n;
     for (int j = part * 256 + tid; j < zero_a_n; j += parts * 256) z[j] = 0.0f;
   }
-  if (zero_b) {
+  if (zero_b && n < M) {  // one texture gradient per MESH
     float* z = zero_b + (int64_t)n * zero_b_n;
     for (int j = part * 256 + tid; j < zero_b_n; j += parts * 256) z[j] = 0.0f;
   }
@@ -483,8 +481,8 @@ __global__ void __launch_bounds__(256) k_project_prep_mesh(
   if (f < F) {
     const float* rm = R + (int64_t)n * 9;
     const float* tv = T + (int64_t)n * 3;
-    const int64_t* fc = faces + (int64_t)n * fstride + (int64_t)f * 3;
-    const float* vp = verts + (int64_t)n * V * 3;
+    const int64_t* fc = faces + (int64_t)m * fstride + (int64_t)f * 3;
+    const float* vp = verts + (int64_t)m * V * 3;
     float c[9];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -577,11 +575,19 @@ struct RasterParams {
   int sum_V;
   const int64_t* faces;
   int64_t fstride;
+  // copy-free pose tiling (ur_render_meshes_*): image n shows mesh n % M under pose n.  M == N (or 0) = one mesh per
+  // image.  Textures, face tables and -- in the backward -- the texture gradient belong to the M meshes.
+  int M;
 };
+
+// the mesh image n shows (see RasterParams::M)
+__device__ __forceinline__ int mesh_of(const RasterParams& P, int n) { return (P.M > 0 && P.M < P.N) ? n % P.M : n; }
 
 // face-UV table row of packed face `fid` of mesh n
 __device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n, int fid) {
-  const int64_t fl = P.fuv_shared ? (int64_t)fid - (P.eqF > 0 ? (int64_t)n * P.eqF : P.first[n]) : (int64_t)fid;
+  int64_t fl = (int64_t)fid;
+  if (P.fuv_shared) fl -= (P.eqF > 0 ? (int64_t)n * P.eqF : P.first[n]);
+  else if (P.M > 0 && P.M < P.N) fl -= (int64_t)(n - n % P.M) * P.eqF;  // tiled poses: the row of mesh n % M
   return P.fuv + fl * 6;
 }
 
@@ -1098,7 +1104,6 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
             wave_lds_handoff();
             // compacted view: lane r holds the r-th face that has pairs
             const int cpre = s_fpre[lane], cend = s_fpre[lane + 1];
-            const unsigned cinfo = s_finfo[lane];
             {
               const int r0 = 0;
               // Lists are not compacted while faces are collected: entries that a later, nearer hiding hit made
@@ -1195,7 +1200,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     //      although pixels have very different depths;  (c) each pixel pulls its items' (alpha, colour) back from
     //      the lanes that computed them, in depth order, and composites: the arithmetic and its order are exactly
     //      those of a per-pixel loop, so the image is bit-identical to the two-stage path.
-    const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+    const float* map = P.maps + (int64_t)mesh_of(P, n) * P.Ht * P.Wt * 3;
     unsigned long long* lds_base = lds_keys;
     unsigned long long* spill_base = spill_keys;
     cnt = s_cnt[lane];
@@ -1576,7 +1581,7 @@ template <int MODE, bool BIGK, bool MASKS> int launch_raster_k(RasterParams P, h
   static LdsSlot lds_slot;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE, BIGK, MASKS>), lds, lds_slot)) return rc;
   const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
-  if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
+  if (blocks > (int64_t)kBinIndex) return fail(UR_ERR_INVALID_ARG, "grid too large");  // bit 30 of an entry = kEmptyBin
   {
     ProfScope prof(MODE == 2 ? UR_PROFILE_RASTER_FWD : UR_PROFILE_OTHER, st);
     hipLaunchKernelGGL((k_raster<MODE, BIGK, MASKS>), dim3((unsigned)blocks), dim3(256), lds, st, P);
@@ -1640,7 +1645,7 @@ void carve_workspace(void* ws, int64_t NF, int N, int H, int W, RasterParams& P,
 bool one_call_prep(int N, int V, int F, int H, int W, int Ht, int Wt) {
   const int64_t nbins = (int64_t)((H + 15) / 16) * ((W + 15) / 16);
   return mesh_prep_ok(F, H, W) && (int64_t)F * 9 <= 0x7fffffffLL && (int64_t)Ht * Wt * 3 <= 0x7fffffffLL &&
-         N <= 0x7fffffff / nbins && N <= 65535;
+         N <= kBinIndex / nbins && N <= 65535;
 }
 
 int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const int64_t* first, int N, int H, int W,
@@ -1654,7 +1659,9 @@ int prep_faces(const float* face_verts, int64_t NF, float blur, int cull, const 
   float4* bbox = const_cast<float4*>(P.bbox);
   float4* rec = const_cast<float4*>(P.rec);
   float* fz = const_cast<float*>(P.fz);
-  const int n_bins = N * ((H + 15) / 16) * ((W + 15) / 16);
+  const int64_t n_bins64 = (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16);
+  if (n_bins64 > (int64_t)kBinIndex) return fail(UR_ERR_INVALID_ARG, "grid too large");
+  const int n_bins = (int)n_bins64;
   if (hipMemsetAsync(binload, 0, (size_t)n_bins * 4, st) != hipSuccess) return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
   if (NF > 0) {
     hipLaunchKernelGGL(k_face_prep, dim3((unsigned)((NF + 255) / 256)), dim3(256), 0, st, face_verts, NF,
@@ -1866,7 +1873,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   // one-call path -- the x / y sum of the vertex at that corner ([mesh][vertex][2])
   auto face_sum = [&](int fid, int c) -> float* {
     if (P.sum_V <= 0) return P.gfv + (int64_t)fid * 9 + (c >> 1) * 3 + (c & 1);
-    const int64_t vid = P.faces[(int64_t)n * P.fstride + (int64_t)(fid - n * P.eqF) * 3 + (c >> 1)];
+    const int64_t vid = P.faces[(int64_t)mesh_of(P, n) * P.fstride + (int64_t)(fid - n * P.eqF) * 3 + (c >> 1)];
     return P.gfv + (((int64_t)n * P.sum_V + vid) << 1) + (c & 1);
   };
   if (sched & kEmptyBin) return;  // no face box reaches the bin: the forward left no rows
@@ -1880,13 +1887,12 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   // the group's layer rows (layout: kRowWords) and one float of scratch per row
   const int4* lay_rows = reinterpret_cast<const int4*>(P.layers + (tile_live ? tile_id : 0) * (int64_t)K * 64 * kRowWords);
   float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 64;  // [item]: dL/dalpha of the layer
-  float* gmap = P.gmaps ? P.gmaps + (int64_t)n * P.Ht * P.Wt * 3 : nullptr;
+  float* gmap = P.gmaps ? P.gmaps + (int64_t)mesh_of(P, n) * P.Ht * P.Wt * 3 : nullptr;
 
   // this pixel's layer count (left by the forward); the group's rows are in pixel-major item order: this pixel's
   // layers are rows [pre, pre + m)
   const int m = (tile_live && live) ? P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] : 0;
   const int incl = wave_scan_add(m);
-  const int pre = incl - m;
   const int total = __builtin_amdgcn_readlane(incl, 63);
   if (!__syncthreads_or(total > 0)) return;  // nothing rendered in this bin
   const int lo = 0, hi = total;
@@ -1966,7 +1972,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
     const int nbatch = (hi - lo + 63) >> 6;
     const int item0 = lo + lane * nbatch;
     const float own_px = pix_to_ndc(W - 1 - x, W, H), own_py = pix_to_ndc(H - 1 - y, H, W);
-    const float* map = P.maps + (int64_t)n * P.Ht * P.Wt * 3;
+    const float* map = P.maps + (int64_t)mesh_of(P, n) * P.Ht * P.Wt * 3;
     const bool clip = P.clip != 0;
     int4 row_next = make_int4(0, 0, 0, 0);
     float ga_next = 0.0f;
@@ -2337,50 +2343,62 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
 }
 
 // The camera's backward from per-VERTEX sums of the NDC x / y gradients (the fused backward's one-call mode leaves
-// them as [mesh][vertex][2]; the layered blend never reads depth, so there is no z term): the per-vertex half of
-// k_project_faces_bwd_mesh, same arithmetic, nothing to gather.  One workgroup per mesh.
+// them as [image][vertex][2]; the layered blend never reads depth, so there is no z term): the per-vertex half of
+// k_project_faces_bwd_mesh, same arithmetic, nothing to gather.  One workgroup per MESH: with M meshes tiled over
+// N = reps * M poses (image n = mesh n % M under pose n) it walks the mesh's poses in ascending order and adds their
+// vertex gradients up in registers (a fixed order: deterministic), so grad_verts is (M,V,3) with no copies of the
+// meshes anywhere; grad_R / grad_T stay per pose.
 __global__ void __launch_bounds__(1024) k_camera_bwd_mesh(const float* __restrict__ verts, const float* __restrict__ R,
-                                                          const float* __restrict__ T, float sx, float sy, int V,
-                                                          const float2* __restrict__ vsum, float* __restrict__ gverts,
-                                                          float* __restrict__ gR, float* __restrict__ gT) {
+                                                          const float* __restrict__ T, float sx, float sy, int V, int M,
+                                                          int reps, const float2* __restrict__ vsum,
+                                                          float* __restrict__ gverts, float* __restrict__ gR,
+                                                          float* __restrict__ gT) {
   __shared__ float part[16 * 12];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const float* r = R + (int64_t)n * 9;
-  const float* t = T + (int64_t)n * 3;
-  float s[12];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  for (int k = 0; k < reps; ++k) {
+    const int n = k * M + m;
+    const float* r = R + (int64_t)n * 9;
+    const float* t = T + (int64_t)n * 3;
+    float s[12];
 #pragma unroll
-  for (int q = 0; q < 12; ++q) s[q] = 0.0f;
-  for (int v = tid; v < V; v += 1024) {
-    const float* p = verts + ((int64_t)n * V + v) * 3;
-    const float2 g = vsum[(int64_t)n * V + v];
-    const float g0 = g.x, g1 = g.y, g2 = 0.0f;
-    const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
-    const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
-    const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
-    const float gv[3] = {g0 * sx / vz, g1 * sy / vz, g2 - (g0 * sx * vx + g1 * sy * vy) / (vz * vz)};
-    if (gverts) {
-      float* go = gverts + ((int64_t)n * V + v) * 3;
+    for (int q = 0; q < 12; ++q) s[q] = 0.0f;
+    for (int v = tid; v < V; v += 1024) {
+      const float* p = verts + ((int64_t)m * V + v) * 3;
+      const float2 g = vsum[(int64_t)n * V + v];
+      const float g0 = g.x, g1 = g.y, g2 = 0.0f;
+      const float vx = ((p[0] * r[0] + p[1] * r[3]) + p[2] * r[6]) + t[0];
+      const float vy = ((p[0] * r[1] + p[1] * r[4]) + p[2] * r[7]) + t[1];
+      const float vz = ((p[0] * r[2] + p[1] * r[5]) + p[2] * r[8]) + t[2];
+      const float gv[3] = {g0 * sx / vz, g1 * sy / vz, g2 - (g0 * sx * vx + g1 * sy * vy) / (vz * vz)};
+      if (gverts) {
+        // vertex v of mesh m belongs to this thread in every pose: a plain read-modify-write, poses in ascending order
+        float* go = gverts + ((int64_t)m * V + v) * 3;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) go[i] = gv[0] * r[i * 3 + 0] + gv[1] * r[i * 3 + 1] + gv[2] * r[i * 3 + 2];
+        for (int i = 0; i < 3; ++i) {
+          const float c = gv[0] * r[i * 3 + 0] + gv[1] * r[i * 3 + 1] + gv[2] * r[i * 3 + 2];
+          go[i] = (k == 0) ? c : go[i] + c;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s[i * 3 + j] += p[i] * gv[j];
+      s[9] += gv[0]; s[10] += gv[1]; s[11] += gv[2];
     }
+    if (!gR && !gT) continue;
+    if (k > 0) __syncthreads();  // the previous pose's partial sums have been read
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) s[i * 3 + j] += p[i] * gv[j];
-    s[9] += gv[0]; s[10] += gv[1]; s[11] += gv[2];
-  }
-  if (!gR && !gT) return;
-#pragma unroll
-  for (int q = 0; q < 12; ++q) {
-    const float v = wave_sum(s[q]);
-    if ((tid & 63) == 63) part[(tid >> 6) * 12 + q] = v;
-  }
-  __syncthreads();
-  if (tid < 12) {
-    float v = 0.0f;
-    for (int w = 0; w < 16; ++w) v += part[w * 12 + tid];
-    float* dst = tid < 9 ? (gR ? gR + (int64_t)n * 9 + tid : nullptr) : (gT ? gT + (int64_t)n * 3 + tid - 9 : nullptr);
-    if (dst) *dst = v;
+    for (int q = 0; q < 12; ++q) {
+      const float w = wave_sum(s[q]);
+      if ((tid & 63) == 63) part[(tid >> 6) * 12 + q] = w;
+    }
+    __syncthreads();
+    if (tid < 12) {
+      float w = 0.0f;
+      for (int wv = 0; wv < 16; ++wv) w += part[wv * 12 + tid];
+      float* dst = tid < 9 ? (gR ? gR + (int64_t)n * 9 + tid : nullptr) : (gT ? gT + (int64_t)n * 3 + tid - 9 : nullptr);
+      if (dst) *dst = w;
+    }
   }
 }
 
@@ -2480,6 +2498,25 @@ __global__ void __launch_bounds__(256) k_blend_fwd(const BlendParamsK P) {
   img[hw] = (g + delta * P.bg[1]) / denom;
   img[2 * hw] = (b + delta * P.bg[2]) / denom;
   img[3 * hw] = 1.0f - alpha;
+}
+
+// LayeredShader(debug=True): the layered blend's per-layer alphas (+ a trailing 1) and the transmittance in front of
+// every layer (renderer.py:185-195), from the same layer_alpha() the blend kernels use
+__global__ void __launch_bounds__(256) k_blend_intermediates(const int32_t* __restrict__ p2f,
+                                                             const float* __restrict__ dists, int64_t npix, int K,
+                                                             float sigma, int mode, float* __restrict__ alpha,
+                                                             float* __restrict__ occ_alpha) {
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  float occ = 1.0f;
+  for (int k = 0; k < K; ++k) {
+    const float a = layer_alpha(dists[pix * K + k], p2f[pix * K + k] >= 0, sigma, mode);
+    alpha[pix * (K + 1) + k] = a;
+    occ_alpha[pix * (K + 1) + k] = occ;
+    occ = occ * (1.0f - a);
+  }
+  alpha[pix * (K + 1) + K] = 1.0f;
+  occ_alpha[pix * (K + 1) + K] = occ;
 }
 
 __global__ void __launch_bounds__(256) k_blend_bwd(const BlendParamsK P) {
@@ -2744,7 +2781,7 @@ int fill_shade_params(ShadeParams& P, const int32_t* p2f, const float* bary, con
 extern "C" {
 
 const char* ur_last_error(void) { return g_err; }
-int ur_abi_version(void) { return 2; }
+int ur_abi_version(void) { return 3; }
 
 int ur_profile_begin(int max_launches) {
   if (max_launches <= 0) return fail(UR_ERR_INVALID_ARG, "max_launches must be > 0");
@@ -2985,6 +3022,19 @@ int ur_blend_colors_backward(const float* grad_image, const float* colors, const
   return check_launch("k_blend_bwd");
 }
 
+int ur_blend_intermediates(const int32_t* pix_to_face, const float* dists, int N, int H, int W, int K, float sigma,
+                           int mode, float* alpha, float* occ_alpha, void* stream) {
+  if (!pix_to_face || !dists || !alpha || !occ_alpha) return fail(UR_ERR_INVALID_ARG, "null pointer");
+  if (N < 0 || H <= 0 || W <= 0 || K <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  if (mode < 0 || mode > 2) return fail(UR_ERR_INVALID_ARG, "bad blend mode %d", mode);
+  if (mode != UR_BLEND_HARD && !(sigma > 0.0f)) return fail(UR_ERR_INVALID_ARG, "sigma must be > 0 for soft blending");
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix == 0) return UR_OK;
+  hipLaunchKernelGGL(k_blend_intermediates, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     pix_to_face, dists, npix, K, sigma, mode, alpha, occ_alpha);
+  return check_launch("k_blend_intermediates");
+}
+
 int ur_selftest_division(uint64_t n, uint32_t seed, uint64_t* mismatches, void* stream) {
   if (!mismatches) return fail(UR_ERR_INVALID_ARG, "null pointer");
   hipLaunchKernelGGL(k_selftest_division, dim3(2048), dim3(256), 0, (hipStream_t)stream, (unsigned long long)n, seed,
@@ -3044,7 +3094,7 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
                             const float* background, const float* ambient, int mode, const int32_t* layers,
                             const void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
                             float* grad_face_verts, float* grad_maps, void* stream, int eqF, int sum_V = 0,
-                            const int64_t* faces = nullptr, int64_t fstride = 0) {
+                            const int64_t* faces = nullptr, int64_t fstride = 0, int M = 0) {
   if (!grad_image || !layers || !workspace || !scratch) return fail(UR_ERR_INVALID_ARG, "null pointer");
   if (scratch_bytes < ur_backward_scratch_bytes(N, H, W, K)) return fail(UR_ERR_WORKSPACE, "scratch too small");
   if (total_faces < 0 || total_faces > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "bad total_faces");
@@ -3061,11 +3111,12 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
   P.gimage = grad_image; P.gfv = grad_face_verts; P.gmaps = grad_maps;
   P.scratch = reinterpret_cast<float*>(scratch);
   P.eqF = eqF;
+  P.M = M;
   if (sum_V > 0 && grad_face_verts && faces) { P.sum_V = sum_V; P.faces = faces; P.fstride = fstride; }
   P.nbx = (W + 15) / 16;
   P.nby = (H + 15) / 16;
   const int64_t blocks = (int64_t)N * P.nbx * P.nby;
-  if (blocks > 0x7fffffffLL) return fail(UR_ERR_INVALID_ARG, "grid too large");
+  if (blocks > (int64_t)kBinIndex) return fail(UR_ERR_INVALID_ARG, "grid too large");
   {
     ProfScope prof(UR_PROFILE_RENDER_BWD, (hipStream_t)stream);
     if (render_bwd_dense(total_faces, N, H, W, Ht, Wt))
@@ -3091,8 +3142,24 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
 
 
 // ---- whole render step over equal-sized meshes: camera + rasterizer + shader in one call each way ------------------
+int ur_render_meshes_can_tile(int V, int F, int H, int W) {
+  return V > 0 && F > 0 && H > 0 && W > 0 && mesh_prep_ok(F, H, W) && (int64_t)F * 9 <= 0x7fffffffLL &&
+         (int64_t)V * 2 <= (int64_t)F * 9;
+}
+
+// n_meshes M: 0 or N = one mesh per image; 0 < M < N (N a multiple of M) = M meshes tiled over the N poses
+static int check_tiling(int N, int& M, int V, int F, int H, int W) {
+  if (M <= 0 || M == N) { M = N; return UR_OK; }
+  if (M > N || N % M != 0) return fail(UR_ERR_INVALID_ARG, "n_meshes = %d does not divide the %d poses", M, N);
+  if (!ur_render_meshes_can_tile(V, F, H, W))
+    return fail(UR_ERR_UNSUPPORTED, "pose tiling (n_meshes < N) needs meshes the per-mesh kernels take "
+                                    "(ur_render_meshes_can_tile): repeat the meshes instead");
+  return UR_OK;
+}
+
 int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t faces_mesh_stride, const float* R,
-                             const float* T, float sx, float sy, int N, int V, int F, const int64_t* mesh_first_face,
+                             const float* T, float sx, float sy, int N, int n_meshes, int V, int F,
+                             const int64_t* mesh_first_face,
                              const int64_t* mesh_num_faces, int H, int W, float blur_radius, int K,
                              int clip_barycentric_coords, int cull_backfaces, const float* maps, const float* face_uvs,
                              int face_uvs_shared, int Ht, int Wt, float sigma, const float* background,
@@ -3108,7 +3175,10 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
                               face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient, mode);
   if (rc) return rc;
   if (N == 0) return UR_OK;
+  int M = n_meshes;
+  if (int trc = check_tiling(N, M, V, F, H, W)) return trc;
   P.eqF = F;
+  P.M = M;
   hipStream_t st = (hipStream_t)stream;
   const int nbins = ((H + 15) / 16) * ((W + 15) / 16);
   const int64_t n_gfv = (int64_t)F * 9, n_gmap = (int64_t)Ht * Wt * 3;
@@ -3126,7 +3196,7 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
     P.masks = masks;
     P.parts = parts;
     hipLaunchKernelGGL(k_project_prep_mesh, dim3((unsigned)parts, (unsigned)N), dim3(256), 0, st, verts, faces, faces_mesh_stride, R, T,
-                       sx, sy, N, V, F, sqrtf(blur_radius), cull_backfaces, H, W, face_verts, const_cast<float4*>(P.bbox),
+                       sx, sy, N, M, V, F, sqrtf(blur_radius), cull_backfaces, H, W, face_verts, const_cast<float4*>(P.bbox),
                        const_cast<float4*>(P.rec), const_cast<float*>(P.fz), binload, masks, zero_grad_face_verts, (int)n_gfv,
                        zero_grad_maps, (int)n_gmap);
     rc = check_launch("k_project_prep_mesh");
@@ -3143,6 +3213,7 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
     if (rc) return rc;
   } else {
     // large meshes: the per-face kernels (a mesh spread over many workgroups, globally sorted schedule)
+    if (M != N) return fail(UR_ERR_UNSUPPORTED, "pose tiling needs the per-mesh prep kernel");  // (check_tiling agrees)
     rc = ur_project_faces(verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, face_verts, stream);
     if (rc) return rc;
     rc = prep_faces(face_verts, NF, blur_radius, cull_backfaces, mesh_first_face, N, H, W, K, workspace, workspace_bytes,
@@ -3159,7 +3230,7 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
 
 int ur_render_meshes_backward(const float* grad_image, const float* verts, const int64_t* faces,
                               int64_t faces_mesh_stride, const float* R, const float* T, float sx, float sy, int N,
-                              int V, int F, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int H, int W,
+                              int n_meshes, int V, int F, const int64_t* mesh_first_face, const int64_t* mesh_num_faces, int H, int W,
                               float blur_radius, int K, int clip_barycentric_coords, const float* maps,
                               const float* face_uvs, int face_uvs_shared, int Ht, int Wt, float sigma,
                               const float* background, const float* ambient, int mode, const int32_t* layers,
@@ -3167,6 +3238,9 @@ int ur_render_meshes_backward(const float* grad_image, const float* verts, const
                               float* grad_face_verts, float* grad_maps, int grads_are_zero, float* grad_verts,
                               float* grad_R, float* grad_T, void* stream) {
   if (N < 0 || F < 0 || Ht <= 0 || Wt <= 0) return fail(UR_ERR_INVALID_ARG, "bad sizes");
+  int M = n_meshes;
+  if (N > 0)
+    if (int trc = check_tiling(N, M, V, F, H, W)) return trc;
   const int64_t NF = (int64_t)N * F;
   const bool geometry = grad_verts || grad_R || grad_T;
   if (geometry && !grad_face_verts) return fail(UR_ERR_INVALID_ARG, "geometry gradients need the grad_face_verts buffer");
@@ -3174,7 +3248,7 @@ int ur_render_meshes_backward(const float* grad_image, const float* verts, const
   if (!grads_are_zero && N > 0) {
     if (grad_face_verts && hipMemsetAsync(grad_face_verts, 0, (size_t)NF * 36, st) != hipSuccess)
       return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
-    if (grad_maps && hipMemsetAsync(grad_maps, 0, (size_t)N * Ht * Wt * 12, st) != hipSuccess)
+    if (grad_maps && hipMemsetAsync(grad_maps, 0, (size_t)M * Ht * Wt * 12, st) != hipSuccess)
       return fail(UR_ERR_LAUNCH, "hipMemsetAsync");
   }
   // One-call path: the fused kernel adds into per-vertex sums (kept in the grad_face_verts buffer, which they must
@@ -3184,14 +3258,15 @@ int ur_render_meshes_backward(const float* grad_image, const float* verts, const
                             clip_barycentric_coords, maps, face_uvs, face_uvs_shared, Ht, Wt, sigma, background, ambient,
                             mode, layers, workspace, workspace_bytes, scratch, scratch_bytes,
                             geometry ? grad_face_verts : nullptr, grad_maps, stream, F, vsum ? V : 0, faces,
-                            faces_mesh_stride);
+                            faces_mesh_stride, M);
   if (rc || !geometry) return rc;
   if (vsum) {
-    if (N > 65535) return fail(UR_ERR_INVALID_ARG, "too many meshes per call");
-    hipLaunchKernelGGL(k_camera_bwd_mesh, dim3((unsigned)N), dim3(1024), 0, st, verts, R, T, sx, sy, V,
+    if (M > 65535) return fail(UR_ERR_INVALID_ARG, "too many meshes per call");
+    hipLaunchKernelGGL(k_camera_bwd_mesh, dim3((unsigned)M), dim3(1024), 0, st, verts, R, T, sx, sy, V, M, N / M,
                        reinterpret_cast<const float2*>(grad_face_verts), grad_verts, grad_R, grad_T);
     return check_launch("k_camera_bwd_mesh");
   }
+  if (M != N) return fail(UR_ERR_UNSUPPORTED, "pose tiling needs per-vertex sums (V * 2 <= F * 9)");  // (check_tiling agrees)
   return ur_project_faces_backward(verts, faces, faces_mesh_stride, R, T, sx, sy, N, V, F, grad_face_verts, grad_verts,
                                    grad_R, grad_T, stream);
 }

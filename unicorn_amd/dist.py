@@ -81,6 +81,35 @@ def timed_steps(step, steps, warmup, world, cuda):
     return max_over_ranks(time.perf_counter() - t0, world, cuda)
 
 
+def timed_blocks(step, steps, warmup, world, cuda, min_seconds=0.3, max_blocks=200):
+    """`warmup` untimed steps, then BLOCKS of exactly `steps` timed steps, each block between two fences and timed as
+    the MAX over ranks, repeated until the blocks add up to `min_seconds` (a region of a few milliseconds is at the
+    mercy of one scheduler hiccup).  Returns (block times in seconds, this rank's own times), identical lengths on
+    every rank: the stop decision is taken on the max-over-ranks times, which every rank holds."""
+    for _ in range(warmup):
+        step()
+    blocks, local = [], []
+    while True:
+        fence(world, cuda)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if cuda:
+            torch.cuda.synchronize()
+        local.append(time.perf_counter() - t0)
+        fence(world, cuda)
+        blocks.append(max_over_ranks(time.perf_counter() - t0, world, cuda))
+        if sum(blocks) >= min_seconds or len(blocks) >= max_blocks:
+            return blocks, local
+
+
+def median_block(blocks, local=None):
+    """the median block's time (the lower middle one of an even count) and, when given, the same block's local time"""
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i])
+    i = order[(len(order) - 1) // 2]
+    return (blocks[i], local[i]) if local is not None else blocks[i]
+
+
 def last_local_elapsed():
     """this rank's own elapsed seconds in the last timed_steps (without the wait for the slowest rank)"""
     return _last_local[0]

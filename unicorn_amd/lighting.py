@@ -3,7 +3,8 @@
 (renderer.py:225-234).  The light models restate the reference's own `diffuse` / `specular`
 (pytorch3d_monkey.py:73-198) and `_apply_lighting` (:34-70); the shading functions restate pytorch3d 0.6.2's
 phong_shading / gouraud_shading / flat_shading (third-party, absent here: parity unpinned, checked against a numpy
-restatement in tests/test_lighting_cpu.py, gouraud end to end in tests/test_gpu_vertex_textures.py).
+restatement in tests/test_lighting_cpu.py, gouraud end to end in tests/test_gpu_vertex_textures.py); `diffuse` and
+`specular` themselves are pinned by outputs of the reference's functions (tests/golden/lighting.npz).
 
 Plain differentiable torch ops on the fragments the HIP rasterizer produced: this is per-fragment arithmetic on a
 visualisation path, the blending that follows is a HIP kernel (ur_blend_colors)."""
@@ -32,24 +33,34 @@ def _bcast(v, like):
     return v.view((v.shape[0],) + (1,) * (like.dim() - 2) + (3,))
 
 
+def _unit(v):
+    """v / max(|v|, 1e-6) along the last axis (what the reference's normalize(p=2, eps=1e-6) computes)"""
+    return v / v.norm(p=2, dim=-1, keepdim=True).clamp_min(1e-6)
+
+
 def diffuse(normals, color, direction):
-    """Lambert term, pytorch3d_monkey.py:73-123"""
-    normals = F.normalize(normals, p=2, dim=-1, eps=1e-6)
-    direction = F.normalize(direction, p=2, dim=-1, eps=1e-6)
-    angle = F.relu(torch.sum(normals * direction, dim=-1))
-    return color * angle[..., None]
+    """Lambert's cosine law: colour * max(n . l, 0) with n, l renormalised (pytorch3d_monkey.py:73-123).  Arguments
+    broadcastable against `normals` (N, ..., 3).  Pinned by tests/golden/lighting.npz (outputs of the reference's own
+    function)."""
+    lambert = torch.relu((_unit(normals) * _unit(direction)).sum(-1, keepdim=True))  # relu: zero slope AT zero
+    return color * lambert
 
 
 def specular(points, normals, direction, color, camera_position, shininess):
-    """pytorch3d_monkey.py:126-198"""
-    normals = F.normalize(normals, p=2, dim=-1, eps=1e-6)
-    direction = F.normalize(direction, p=2, dim=-1, eps=1e-6)
-    cos_angle = torch.sum(normals * direction, dim=-1)
-    mask = (cos_angle > 0).to(torch.float32)
-    view_direction = F.normalize(camera_position - points, p=2, dim=-1, eps=1e-6)
-    reflect_direction = -direction + 2 * (cos_angle[..., None] * normals)
-    alpha = F.relu(torch.sum(view_direction * reflect_direction, dim=-1)) * mask
-    return color * torch.pow(alpha, shininess)[..., None]
+    """colour * max(v . r, 0)^shininess on the lit side of the surface, r = the light direction mirrored at the
+    normal, v = the unit vector towards the camera (pytorch3d_monkey.py:126-198).  Pinned by tests/golden/lighting.npz."""
+    n, l = _unit(normals), _unit(direction)
+    n_dot_l = (n * l).sum(-1, keepdim=True)
+    mirrored = 2 * (n_dot_l * n) - l
+    towards_eye = _unit(camera_position - points)
+    lit_side = (n_dot_l > 0).to(points.dtype)
+    highlight = torch.relu((towards_eye * mirrored).sum(-1, keepdim=True)) * lit_side
+    shininess = torch.as_tensor(shininess, dtype=points.dtype, device=points.device)
+    if shininess.dim() == 1:      # one exponent per batch element
+        shininess = shininess.view((-1,) + (1,) * (points.dim() - 1))
+    elif shininess.dim() > 1:     # one per point
+        shininess = shininess.unsqueeze(-1)
+    return color * highlight.pow(shininess)
 
 
 def light_terms(lights, materials, points, normals, camera_center):

@@ -44,14 +44,28 @@ _SIGNATURES = {
     "ur_backward_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ur_render_layered_backward": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _f, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp,
                                         _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
-    "ur_render_meshes_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _i, _i, _f, _i, _i, _i,
-                                      _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ur_render_meshes_backward": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _i, _i, _f, _i, _i,
-                                       _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i,
-                                       _vp, _vp, _vp, _vp]),
+    "ur_render_meshes_can_tile": (_i, [_i, _i, _i, _i]),
+    "ur_blend_intermediates": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "ur_render_meshes_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _i, _i,
+                                      _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                      _vp]),
+    "ur_render_meshes_backward": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _i,
+                                       _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp,
+                                       _i, _vp, _vp, _vp, _vp]),
     "ur_shade_blend_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i,
                                      _vp, _vp, _vp, _vp]),
 }
+
+
+def source_hash():
+    """sha256 over the kernel sources the library is built from (ur_render.hip + ur_device.h): stamps counter files,
+    so that a counter taken on other kernels is not mistaken for this build's"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("ur_render.hip", "ur_device.h"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def exported_symbols():
@@ -311,7 +325,7 @@ def _rgb(v):
     a = _rgb_cache.get(key)
     if a is None:
         if len(_rgb_cache) > 256:
-            _rgb_cache.clear()
+            _rgb_cache.pop(next(iter(_rgb_cache)))  # one entry out (the oldest); callers hold their arrays anyway
         a = _rgb_cache[key] = _F3(*[float(x) for x in key])
     return a
 
@@ -427,8 +441,10 @@ def render_layered_backward(grad_image, mesh_first_face, mesh_num_faces, total_f
     return gfv, gmaps
 
 
-def _rgb_ptr(v):
-    return None if v is None else ctypes.addressof(_rgb(v))
+def _rgb_ptr(arr):
+    """address of a colour array from _rgb(); the CALLER keeps `arr` in a local for the duration of the C call (the
+    cache above may evict it meanwhile)"""
+    return None if arr is None else ctypes.addressof(arr)
 
 
 _step_layouts = {}
@@ -467,8 +483,9 @@ def render_meshes_forward(verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_
     allocator calls and two C calls, so each allocation saved shows in the eager rate.  `grad_maps`: the texture
     gradient's buffer, cleared on the way (None unless need_map_grads); the accumulator is cleared likewise when
     need_geometry_grads."""
-    N, V = verts.shape[:2]
-    F, fstride = _faces_layout(faces, N)
+    M, V = verts.shape[:2]   # M meshes shown under N = R.shape[0] poses (image n = mesh n % M; M == N: one each)
+    N = int(R.shape[0])
+    F, fstride = _faces_layout(faces, M)
     H, W = image_size
     K = int(faces_per_pixel)
     Ht, Wt = maps.shape[1:3]
@@ -478,12 +495,13 @@ def render_meshes_forward(verts, faces, R, T, sx, sy, mesh_first_face, mesh_num_
     state = torch.empty(total, dtype=torch.uint8, device=dev)
     gmaps = torch.empty_like(maps) if need_map_grads else None
     base = state.data_ptr()
+    bg_arr, amb_arr = _rgb(background), _rgb(ambient)  # held here until the call has returned
     _call("ur_render_meshes_forward", verts,
             _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride, _ptr(R, torch.float32),
-            _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(mesh_first_face, torch.int64),
+            _ptr(T, torch.float32), sx, sy, N, M, V, F, _ptr(mesh_first_face, torch.int64),
             _ptr(mesh_num_faces, torch.int64), H, W, float(blur_radius), K, int(clip_barycentric_coords),
             int(cull_backfaces), _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt,
-            float(sigma), _rgb_ptr(background), _rgb_ptr(ambient), int(mode), base, image.data_ptr(), base + o_lay,
+            float(sigma), _rgb_ptr(bg_arr), _rgb_ptr(amb_arr), int(mode), base, image.data_ptr(), base + o_lay,
             base + o_acc if need_geometry_grads else None, None if gmaps is None else gmaps.data_ptr(), base + o_ws,
             ws_b, _stream(verts))
     return image, state, gmaps
@@ -496,8 +514,9 @@ def render_meshes_backward(grad_image, verts, faces, R, T, sx, sy, mesh_first_fa
     """-> grad_verts, grad_R, grad_T, grad_maps (None where not needed).  `state` / `grad_maps`: what the forward
     returned; grads_are_zero: they still are as the forward left them (False on a second backward through the same
     step: the call then clears the accumulators itself, and grad_maps may be None = allocate one)."""
-    N, V = verts.shape[:2]
-    F, fstride = _faces_layout(faces, N)
+    M, V = verts.shape[:2]
+    N = int(R.shape[0])
+    F, fstride = _faces_layout(faces, M)
     H, W = image_size
     K = int(faces_per_pixel)
     Ht, Wt = maps.shape[1:3]
@@ -510,16 +529,34 @@ def render_meshes_backward(grad_image, verts, faces, R, T, sx, sy, mesh_first_fa
     gR = torch.empty_like(R) if need_R else None
     gT = torch.empty_like(T) if need_T else None
     base = state.data_ptr()
+    bg_arr, amb_arr = _rgb(background), _rgb(ambient)  # held here until the call has returned
     _call("ur_render_meshes_backward", verts,
             _ptr(grad_image, torch.float32), _ptr(verts, torch.float32), _ptr(faces, torch.int64), fstride,
-            _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, V, F, _ptr(mesh_first_face, torch.int64),
+            _ptr(R, torch.float32), _ptr(T, torch.float32), sx, sy, N, M, V, F, _ptr(mesh_first_face, torch.int64),
             _ptr(mesh_num_faces, torch.int64), H, W, float(blur_radius), K, int(clip_barycentric_coords),
             _ptr(maps, torch.float32), _ptr(face_uvs, torch.float32), int(face_uvs_shared), Ht, Wt, float(sigma),
-            _rgb_ptr(background), _rgb_ptr(ambient), int(mode), base + o_lay, base + o_ws, ws_b, base + o_scr, scr_b,
+            _rgb_ptr(bg_arr), _rgb_ptr(amb_arr), int(mode), base + o_lay, base + o_ws, ws_b, base + o_scr, scr_b,
             base + o_acc if geometry else None, grad_maps.data_ptr() if need_maps else None, int(bool(grads_are_zero)),
             None if gv is None else gv.data_ptr(), None if gR is None else gR.data_ptr(),
             None if gT is None else gT.data_ptr(), _stream(verts))
     return gv, gR, gT, (grad_maps if need_maps else None)
+
+
+def can_tile(V, F, H, W):
+    """may B meshes be shown under K*B poses without copying them (ur_render_meshes_* with n_meshes < N)?"""
+    return bool(_sized("ur_render_meshes_can_tile", int(V), int(F), int(H), int(W)))
+
+
+def blend_intermediates(pix_to_face, dists, sigma, mode):
+    """-> alpha, occ_alpha (N,H,W,K+1): the layered blend's per-layer intermediates (LayeredShader debug=True)"""
+    N, H, W, K = pix_to_face.shape
+    alpha = torch.empty(N, H, W, K + 1, dtype=torch.float32, device=dists.device)
+    occ = torch.empty_like(alpha)
+    with _on(dists):
+        _check(lib().ur_blend_intermediates(_ptr(pix_to_face, torch.int32), _ptr(dists, torch.float32), N, H, W, K,
+                                            float(sigma), int(mode), _ptr(alpha), _ptr(occ), _stream(dists)),
+               "ur_blend_intermediates")
+    return alpha, occ
 
 
 def mesh_regularizers(verts, edge_quads, nbr_offsets, nbr_index, need_grad=True):

@@ -208,17 +208,24 @@ class LayeredShader(nn.Module):
     def render_fused(self, rasterizer, meshes, R=None, T=None, **kwargs):
         bp = kwargs.get("blend_params", self.blend_params)
         rs = kwargs.get("raster_settings", rasterizer.raster_settings)
+        n_images = len(meshes)
+        one_call = meshes.equisized and not rs.cull_backfaces
+        base = getattr(meshes, "tile_base", None)
+        if base is not None and one_call and native.can_tile(base.verts_padded().shape[1],
+                                                             base.faces_padded().shape[1], *rs.image_size):
+            # utils.mesh.repeat(meshes, K) (unicorn.py:232-233) without the copies: the B meshes as they are, the K*B
+            # poses index them (image n = mesh n % B); the gradients land in the B meshes' own tensors
+            meshes = base
         tex = meshes.textures
         ambient = _rgb3(self.lights.ambient_color)
         ambient = None if ambient == (1.0, 1.0, 1.0) else ambient
         face_uvs, shared = tex.faces_verts_uvs()
-        if meshes.equisized and not rs.cull_backfaces:
+        if one_call:
             # the reference's case (one template topology): camera + rasterizer + shader in one call each way
             sx, sy = rasterizer.cameras.focal_scale()
             verts, faces = meshes.verts_padded(), meshes.faces_padded()
-            N, Fn = faces.shape[:2]
             faces = rasterizer._shared_faces(faces)
-            first, nf = rasterizer._mesh_index(N, Fn, verts.device)
+            first, nf = rasterizer._mesh_index(n_images, faces.shape[-2], verts.device)
             return ops.render_meshes(_f32(verts), _f32(tex.maps_padded()), _f32(R), _f32(T), faces,
                                      sx, sy, first, nf, rs.image_size, rs.blur_radius, rs.faces_per_pixel,
                                      rs.clip_barycentric_coords, _f32(face_uvs), shared, bp.sigma,
@@ -230,21 +237,15 @@ class LayeredShader(nn.Module):
 
     def debug_outputs(self, colors, fragments, bp, image):
         """debug=True (renderer.py:199-200): the blend's intermediates next to the image -- colours with the
-        background appended as layer K, alpha with a trailing 1, and the transmittance in front of every layer.
-        Inspection only: a few elementwise torch ops over the fragments; the image itself comes from the kernel."""
+        background appended as layer K, the layers' alphas with a trailing 1, and the transmittance in front of every
+        layer.  Inspection only; alphas and transmittances come from the library (ur_blend_intermediates: the blend
+        kernels' own alpha function), the image from the blend kernel."""
         N, H, W, K = fragments.dists.shape
-        mask = fragments.pix_to_face_i32 >= 0
-        if bp.sigma == 0:
-            alpha = (fragments.dists <= 0).float() * mask
-        elif self.clip_inside:
-            alpha = torch.exp(-fragments.dists.clamp(0) / bp.sigma) * mask
-        else:
-            alpha = torch.sigmoid(-fragments.dists / bp.sigma) * mask
-        one = torch.ones(N, H, W, 1, device=alpha.device)
-        occ_alpha = torch.cat([one, torch.cumprod(1.0 - alpha, dim=-1)], dim=-1)
+        alpha, occ_alpha = native.blend_intermediates(fragments.pix_to_face_i32, fragments.dists.detach().contiguous(),
+                                                      bp.sigma, self.blend_mode(bp))
         bg = torch.tensor(_rgb3(bp.background_color), dtype=torch.float32, device=alpha.device)
-        colors = torch.cat([colors, bg[None, None, None, None].expand(N, H, W, 1, -1)], dim=-2)
-        return colors, torch.cat([alpha, one], dim=-1), occ_alpha, image
+        colors = torch.cat([colors, bg.expand(N, H, W, 1, 3)], dim=-2)
+        return colors, alpha, occ_alpha, image
 
     def forward(self, fragments, meshes, **kwargs):
         bp = kwargs.get("blend_params", self.blend_params)
@@ -379,24 +380,31 @@ def _from_spec(spec, types, default_name):
 class Renderer(nn.Module):
     """Drop-in for the reference's `Renderer` (renderer.py:25-116).  Two pipelines share one camera and one set of
     lights: `renderer` (soft rasterization for training: K faces per pixel, blur radius ln(1/1e-4 - 1) * sigma) and
-    `viz_renderer` (hard, one face per pixel, 2x supersampled).  An option left at None takes the reference's default
-    and stays out of `init_kwargs`, which therefore returns exactly what the caller passed."""
+    `viz_renderer` (hard, one face per pixel, 2x supersampled).  Options are read like the reference reads them
+    (`kwargs.get(name, default)`, renderer.py:30-52): a key the class does not know is ignored for construction and
+    kept in `init_kwargs`, which returns exactly what the caller passed (configs of forks and `model_kwargs` of
+    checkpoints travel through it, unicorn.py:46-47)."""
 
-    def __init__(self, img_size, *, cameras=None, lights=None, sigma=None, background_color=None, faces_per_pixel=None,
-                 layered_shader=None, clip_inside=None, shading_type=None, debug=None, viz_size=None):
+    def __init__(self, img_size, **kwargs):
         super().__init__()
-        options = dict(cameras=cameras, lights=lights, sigma=sigma, background_color=background_color,
-                       faces_per_pixel=faces_per_pixel, layered_shader=layered_shader, clip_inside=clip_inside,
-                       shading_type=shading_type, debug=debug, viz_size=viz_size)
-        self._passed = deepcopy({k: v for k, v in options.items() if v is not None})
-        self.config = cfg = RenderConfig(**deepcopy(self._passed))
-        self.cameras = _from_spec(cfg.cameras, CAMERA_TYPES, 'fov')
-        self.lights = _from_spec(cfg.lights, LIGHT_TYPES, 'ambient')
-        # what reset_default_lights() goes back to after update_lights() (the eye-light GIFs, renderer.py:225-251)
-        self._light_defaults = {attr: getattr(self.lights, attr) for _, attr in LIGHT_FIELDS if hasattr(self.lights, attr)}
+        self._init_kwargs = deepcopy(kwargs)
+        known = {f for f in RenderConfig.__dataclass_fields__}
+        self.config = cfg = RenderConfig(**deepcopy({k: v for k, v in kwargs.items() if k in known}))
+        self.init_cameras(**cfg.cameras)
+        self.init_lights(**cfg.lights)
         viz = _pair(cfg.viz_size)
         self.renderer = self._pipeline(MeshRenderer, _pair(img_size), cfg.faces_per_pixel, cfg.sigma)
         self.viz_renderer = self._pipeline(VizMeshRenderer, (2 * viz[0], 2 * viz[1]), 1, 0.0)
+
+    def init_cameras(self, **kwargs):
+        """renderer.py:59-63"""
+        self.cameras = _from_spec(kwargs, CAMERA_TYPES, 'fov')
+
+    def init_lights(self, **kwargs):
+        """renderer.py:65-74; what reset_default_lights() goes back to after update_lights() (the eye-light GIFs,
+        renderer.py:225-251) is remembered for every kind of light, not only the directional one"""
+        self.lights = _from_spec(kwargs, LIGHT_TYPES, 'ambient')
+        self._light_defaults = {attr: getattr(self.lights, attr) for _, attr in LIGHT_FIELDS if hasattr(self.lights, attr)}
 
     def _pipeline(self, kind, image_size, faces_per_pixel, sigma):
         """rasterizer + shader for one (size, K, sigma): renderer.py:45-49 (training) and :51-57 (visualisation).  The
@@ -414,7 +422,7 @@ class Renderer(nn.Module):
 
     @property
     def init_kwargs(self):
-        return deepcopy(self._passed)
+        return deepcopy(self._init_kwargs)
 
     def forward(self, meshes, R, T, viz_purpose=False):
         """-> (N, 4, H, W) RGBA"""

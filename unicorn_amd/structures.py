@@ -379,24 +379,102 @@ def join_meshes_as_batch(meshes):
     return Meshes(verts, faces)
 
 
+class TiledTexturesUV(TexturesUV):
+    """The textures of `repeat(mesh, reps)`: the base textures `reps` times in tile order, WITHOUT the copy until a
+    caller asks for the repeated tensors (the fused renderer never does: it indexes the base maps)."""
+
+    def __init__(self, base, reps):
+        self.tile_base, self.tile_reps = base, reps
+        self._tiled = None
+        self._num_faces_per_mesh = base._num_faces_per_mesh * reps
+        self.device = base.device
+
+    def _materialise(self):
+        if self._tiled is None:
+            b, n = self.tile_base, self.tile_reps
+            rep = (lambda t: t[:1].expand(len(b) * n, -1, -1)) if b._shared_tables() else (lambda t: t.repeat(n, 1, 1))
+            self._tiled = (b.maps_padded().repeat(n, 1, 1, 1), rep(b.faces_uvs_padded()), rep(b.verts_uvs_padded()))
+        return self._tiled
+
+    _maps = property(lambda self: self._materialise()[0])
+    _faces_uvs = property(lambda self: self._materialise()[1])
+    _verts_uvs = property(lambda self: self._materialise()[2])
+
+    def __len__(self):
+        return len(self.tile_base) * self.tile_reps
+
+
+class TiledMeshes(Meshes):
+    """`repeat(mesh, reps)` for equal-sized meshes: reps copies in torch `repeat` (tile) order -- mesh i of the result
+    is base mesh i % B -- held as the base meshes plus the count.  The fused renderer reads the base tensors through
+    that index (ur_render_meshes_* with n_meshes = B: no copy of verts, faces or texture maps, and the gradients of
+    all poses of a mesh are summed by the kernels); any other consumer gets ordinary repeated tensors, made on first
+    use."""
+
+    def __init__(self, base, reps):
+        self.tile_base, self.tile_reps = base, int(reps)
+        self._N = len(base) * self.tile_reps
+        self._equisized = True
+        self._verts_list = self._faces_list = None
+        self._tiled_verts = self._tiled_faces = None
+        tex = base.textures
+        if isinstance(tex, TexturesUV):
+            self.textures = TiledTexturesUV(tex, self.tile_reps)
+        elif isinstance(tex, TexturesVertex):
+            self.textures = TexturesVertex(tex.verts_features_padded().repeat(self.tile_reps, 1, 1))
+        elif tex is None:
+            self.textures = None
+        else:
+            raise NotImplementedError
+        self._cache = {}
+
+    @property
+    def _verts_padded(self):
+        if self._tiled_verts is None:
+            self._tiled_verts = self.tile_base.verts_padded().repeat(self.tile_reps, 1, 1)
+        return self._tiled_verts
+
+    @_verts_padded.setter
+    def _verts_padded(self, value):  # offset_verts_ / scale_verts_ assign new vertices: the tiling ends there
+        if self.tile_base is not None:
+            _ = self._faces_padded  # (made from the base while it is still known)
+        self._tiled_verts = value
+        self.tile_base = None
+
+    @property
+    def _faces_padded(self):
+        if self._tiled_faces is None:
+            f = self.tile_base.faces_padded()
+            # one shared topology stays a batch-expanded view (stride 0); per-mesh tables are repeated
+            self._tiled_faces = f[:1].expand(self._N, -1, -1) if f.stride(0) == 0 else f.repeat(self.tile_reps, 1, 1)
+        return self._tiled_faces
+
+    @_faces_padded.setter
+    def _faces_padded(self, value):
+        self._tiled_faces = value
+
+    @property
+    def device(self):
+        return self.tile_base.device if self.tile_base is not None else self._tiled_verts.device
+
+
 def repeat(mesh, N):
     """N copies in torch `repeat` (tile) order -- the convention of the reference's utils/mesh.py:43-71 (candidate
-    poses are K-major, unicorn.py:295-304).  One tensor op per field instead of K*B clones."""
+    poses are K-major, unicorn.py:295-304).  Equal-sized meshes are not copied at all (TiledMeshes: the renderer
+    indexes the B meshes with image % B); others take one list operation."""
     assert N >= 1
     if N == 1:
         return mesh
+    if mesh.equisized and len(mesh) > 0:
+        return TiledMeshes(mesh, N)
     tex = mesh.textures
     if isinstance(tex, TexturesVertex):
         new_tex = TexturesVertex(tex.verts_features_padded().repeat(N, 1, 1))
     elif isinstance(tex, TexturesUV):
-        shared = tex._shared_tables()
-        rep = (lambda t: t[:1].expand(len(tex) * N, -1, -1)) if shared else (lambda t: t.repeat(N, 1, 1))
-        new_tex = TexturesUV(tex.maps_padded().repeat(N, 1, 1, 1), rep(tex.faces_uvs_padded()),
-                             rep(tex.verts_uvs_padded()))
+        new_tex = TexturesUV(tex.maps_padded().repeat(N, 1, 1, 1), tex.faces_uvs_padded().repeat(N, 1, 1),
+                             tex.verts_uvs_padded().repeat(N, 1, 1))
     elif tex is None:
         new_tex = None
     else:
         raise NotImplementedError
-    if mesh.equisized:
-        return Meshes(mesh.verts_padded().repeat(N, 1, 1), mesh.faces_padded().repeat(N, 1, 1), new_tex)
     return Meshes(mesh.verts_list() * N, mesh.faces_list() * N, new_tex)
