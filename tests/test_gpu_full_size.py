@@ -88,6 +88,27 @@ def test_headline_batch_b32_128px_k50():
     b.check_against_oracle(out, g1, c1, picks=(0, 17, 31))
 
 
+def test_four_and_eight_wave_bins_agree():
+    """The fused kernels run a bin with four waves of 64 pixels, or -- launches too small to fill the chip that way,
+    N x bins <= 1024 -- with eight waves of 32 pixels, no bin schedule and an eight-wave backward.  Same pictures bit
+    for bit, same gradients to rounding: a batch of 80 images (64x64: 1280 bins, four-wave) against its own slices of
+    16 (256 bins, eight-wave), and against the oracle."""
+    b = Batch(80, 2, 64, 50, seed=6, tex=32)
+    out = b.render().detach()
+    cot = np.random.RandomState(2).randn(*out.shape).astype(np.float32)
+    g_all = b.grads(torch.from_numpy(cot).to(DEV))
+    for lo in (0, 48, 64):
+        sl = slice(lo, lo + 16)
+        assert torch.equal(out[sl], b.render(sl).detach())
+        for t in b.leaves:
+            t.grad = None
+        b.render(sl).backward(torch.from_numpy(cot[sl]).to(DEV))
+        for full, leaf in zip(g_all, b.leaves):
+            assert rel_err(leaf.grad[sl].cpu().numpy(), full[sl].cpu().numpy()) <= 2e-5
+            assert float(leaf.grad[:lo].abs().max() if lo else 0.0) == 0.0   # nothing leaks into other meshes
+    b.check_against_oracle(out, g_all, cot, picks=(3, 79))
+
+
 def test_pose_step_batch_b192_64px_k50():
     """cfg2 pose step: 32 meshes x 6 pose candidates tiled K-major (utils/mesh.py:43-71, unicorn.py:232-233), 64x64"""
     from unicorn_amd.structures import repeat

@@ -48,12 +48,6 @@ def test_vertex_sums_that_do_not_fit_the_face_buffer():
     assert float(verts.grad[:, ~used.cuda()].abs().max()) == 0.0
 
 
-def _vertex_at_view(sc, n, vertex, view_xyz):
-    """move one vertex of mesh n so that its VIEW coordinates under (R[n], T[n]) are view_xyz (view = X @ R + T)"""
-    R, T = sc["R"][n].double(), sc["T"][n].double()
-    sc["verts"][n, vertex] = ((torch.tensor(view_xyz, dtype=torch.float64) - T) @ R.t()).float()
-
-
 @pytest.mark.parametrize("hw", [(128, 128), (16, 4112)], ids=lambda hw: f"{hw[0]}x{hw[1]}")
 def test_vertex_next_to_the_camera_plane(hw):
     """a vertex at view depth ~1e-9 has NDC coordinates of ~1e9; its faces' blur-expanded boxes are huge,
@@ -65,9 +59,13 @@ def test_vertex_next_to_the_camera_plane(hw):
     from unicorn_amd import synth
     from unicorn_amd.renderer import Renderer
     sc = synth.make_scene(2, level=1, tex_size=16, seed=21)
-    _vertex_at_view(sc, 0, 5, (0.31, -0.17, 1e-9))
-    _vertex_at_view(sc, 1, 9, (-0.4, 0.23, 3e-9))
-    # (the float32 round trip through world space leaves |z| ~ 1e-7 at worst: still NDC coordinates beyond 1e6)
+    # identity camera, the meshes pushed 2.7 units down the view axis: a vertex's view depth is then its own z
+    # coordinate, exactly, and two vertices are put 1e-9 / 3e-9 in front of the camera plane (NDC x, y ~ 1e9)
+    sc["R"][:] = torch.eye(3)
+    sc["T"][:] = 0.0
+    sc["verts"][..., 2] += 2.7
+    sc["verts"][0, 5] = torch.tensor([0.31, -0.17, 1e-9])
+    sc["verts"][1, 9] = torch.tensor([-0.4, 0.23, 3e-9])
     dev = torch.device("cuda:0")
     faces, uvs = sc["faces"].to(dev), sc["verts_uvs"].to(dev)
     fb, ub = faces[None].expand(2, -1, -1), uvs[None].expand(2, -1, -1)
@@ -88,6 +86,7 @@ def test_vertex_next_to_the_camera_plane(hw):
     fv = np.stack([ndc[n][sc["faces"].numpy()] for n in range(2)]).reshape(-1, 3, 3)
     p2f = orc.rasterize(fv, 2, H, W, orc.blur_radius_for(1e-3), K)[0]
     assert np.array_equal(frag.pix_to_face_i32.cpu().numpy(), p2f)
+    assert np.abs(fv[np.unique(p2f[p2f >= 0])]).max() > 1e8   # faces of the near-plane vertices do own pixels
 
 
 def test_vertex_on_the_camera_plane_fused_equals_two_stage():

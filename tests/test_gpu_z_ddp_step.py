@@ -26,37 +26,59 @@ def _make(device):
     return model, imgs
 
 
-def _rank_main(rank, world, rdzv_path, out_path):
+def _log_dir():
+    """where the ranks' progress notes and stack dumps go: under gpurun_out/ on the GPU box (merged back after the
+    call, so they survive a kill of the whole run), else the system's temporary directory"""
+    root = os.environ.get("GRAFT_REPO_ROOT")
+    d = os.path.join(root, "gpurun_out") if root and os.path.isdir(root) else tempfile.gettempdir()
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _rank_main(rank, world, rdzv_path, out_path, log_dir):
+    import datetime
     import faulthandler
     import time
+    # (child only) c10d / gloo say what they are doing; every collective names itself if it gives up
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), TORCH_DISTRIBUTED_DEBUG="INFO", GLOO_LOG_LEVEL="INFO",
+                      TORCH_CPP_LOG_LEVEL="INFO")
     import torch.distributed as dist
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     from examples.train_step import train_steps
     from unicorn_amd import dist as udist
-    # a rank that is still busy after 80 s says where (all threads) before the parent's limit kills it
-    faulthandler.dump_traceback_later(80, exit=False)
+    # Everything a rank can say about where it stands goes to ONE file per rank that outlives the process: progress
+    # notes as they happen (line buffered), this rank's stderr (c10d / gloo / MIOpen messages), and -- if the rank is
+    # still busy after 60 s -- the stacks of all its threads (again every 20 s after that).
+    log = open(os.path.join(log_dir, f"ddp_step_rank{rank}.log"), "w", buffering=1)
+    os.dup2(log.fileno(), 2)
+    faulthandler.dump_traceback_later(60, repeat=True, file=log, exit=False)
     t_start = time.perf_counter()
 
-    def mark(what):  # progress notes the parent quotes if the ranks overrun
-        with open(f"{out_path}.rank{rank}.log", "a") as f:
-            f.write(f"{time.perf_counter() - t_start:7.1f} s  {what}\n")
+    def mark(what):
+        log.write(f"[{time.perf_counter() - t_start:7.1f} s] rank {rank}: {what}\n")
     mark("started")
     udist.isolate_miopen_cache(rank)  # the ranks share the box: each gets its own MIOpen database / kernel cache
     udist.gloo_on_loopback()          # no host-name lookups for gloo's sockets (the box's name does not resolve)
     t0 = time.perf_counter()
-    # rendezvous through a file in the test's own temporary directory: no store port that another process on the
-    # host could hold (a run of the suite once sat in this call until the bounded wait below gave up)
-    dist.init_process_group("gloo", init_method="file://" + rdzv_path, rank=rank, world_size=world)
+    # rendezvous through a file in the test's own temporary directory (no store port another process could hold); a
+    # collective that cannot complete RAISES after 45 s, naming itself, instead of sitting there until the parent
+    # kills the rank
+    dist.init_process_group("gloo", init_method="file://" + rdzv_path, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=45))
     mark("process group up")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     model, imgs = _make(dev)
-    mark("model on the GPU")
+    mark("model and target images on the GPU (first renderer call done)")
+    assert model.pose_step is True  # both ranks start in the same phase of the alternate optimisation: the sets of
+    #                                 unused parameters DDP sees agree across ranks in every iteration
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
-    mark("DDP wrapper built")
-    losses = train_steps(ddp, imgs[rank * PER_RANK:(rank + 1) * PER_RANK], STEPS)
-    mark("training steps done")
+    mark("DDP wrapper built (parameter broadcast over gloo done)")
+    losses = []
+    for i in range(STEPS):
+        losses += train_steps(ddp, imgs[rank * PER_RANK:(rank + 1) * PER_RANK], 1)
+        torch.cuda.synchronize()
+        mark(f"training step {i} done (loss {losses[-1]:.5f})")
     print(f"rank {rank}: {STEPS} DDP steps (MIOpen convolutions) after {time.perf_counter() - t0:.1f} s", flush=True)
     t = torch.tensor(losses, device=dev)
     dist.all_reduce(t)
@@ -64,6 +86,7 @@ def _rank_main(rank, world, rdzv_path, out_path):
         torch.save({"params": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                     "losses": (t / world).cpu()}, out_path)
     dist.barrier()
+    mark("results saved, leaving")
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
 
@@ -73,7 +96,8 @@ def test_two_rank_ddp_step_equals_single_process_training():
     from examples.train_step import train_steps
     with tempfile.TemporaryDirectory() as tmp:
         out_path = os.path.join(tmp, "rank0.pt")
-        ctx = mp.spawn(_rank_main, args=(2, os.path.join(tmp, "rendezvous"), out_path), nprocs=2, join=False)
+        log_dir = _log_dir()
+        ctx = mp.spawn(_rank_main, args=(2, os.path.join(tmp, "rendezvous"), out_path, log_dir), nprocs=2, join=False)
         for _ in range(100):                       # bounded wait: never hang the suite on a stuck rank
             if ctx.join(timeout=1.0):
                 break
@@ -83,10 +107,11 @@ def test_two_rank_ddp_step_equals_single_process_training():
             notes = []
             for r in range(2):
                 try:
-                    notes.append(f"rank {r}:\n" + open(f"{out_path}.rank{r}.log").read())
+                    notes.append(f"rank {r}:\n" + open(os.path.join(log_dir, f"ddp_step_rank{r}.log")).read()[-6000:])
                 except OSError:
                     notes.append(f"rank {r}: no progress note")
-            pytest.fail("DDP ranks did not finish within 100 s\n" + "\n".join(notes))
+            pytest.fail(f"DDP ranks did not finish within 100 s (full notes: {log_dir}/ddp_step_rank*.log)\n"
+                        + "\n".join(notes))
         # the same training in this process on the whole batch (after the ranks), MIOpen convolutions on both sides
         model, imgs = _make(torch.device("cuda", 0))
         losses = train_steps(model, imgs, STEPS)

@@ -623,11 +623,12 @@ struct KeyList {
   unsigned long long* lds;    // + lane
   unsigned long long* spill;  // + lane
   int cap;
+  int stride;                 // pixels per group: entries of one slot lie `stride` keys apart
   __device__ __forceinline__ unsigned long long get(int i) const {
-    return i < cap ? lds[(size_t)i * 64] : spill[(size_t)(i - cap) * 64];
+    return i < cap ? lds[(size_t)i * stride] : spill[(size_t)(i - cap) * stride];
   }
   __device__ __forceinline__ void put(int i, unsigned long long v) const {
-    if (i < cap) lds[(size_t)i * 64] = v; else spill[(size_t)(i - cap) * 64] = v;
+    if (i < cap) lds[(size_t)i * stride] = v; else spill[(size_t)(i - cap) * stride] = v;
   }
   // Keep, in order, the entries <= bound of this lane's first n entries (lanes with !need keep everything and
   // return n); mx = the largest n among the lanes that need it (wave-uniform).  Entries are read eight at a time
@@ -655,7 +656,7 @@ struct KeyList {
 __device__ __attribute__((noinline)) void full_list_insert(unsigned long long pending, unsigned long long over_key,
                                                            int over_pl, unsigned long long* lds_keys,
                                                            unsigned long long* spill_keys, unsigned long long* thr,
-                                                           int cap, int KL) {
+                                                           int cap, int KL, int stride) {
   const int lane = threadIdx.x & 63;
   while (pending) {
     wave_lds_handoff();  // lane 0's replacement of the last round is part of the list the next round scans
@@ -668,7 +669,7 @@ __device__ __attribute__((noinline)) void full_list_insert(unsigned long long pe
     unsigned long long m1 = 0ull, m2 = 0ull;
     int i1 = 0;
     for (int j = lane; j < KL; j += 64) {
-      const unsigned long long v = j < cap ? lds_keys[(size_t)j * 64 + opl] : spill_keys[(size_t)(j - cap) * 64 + opl];
+      const unsigned long long v = j < cap ? lds_keys[(size_t)j * stride + opl] : spill_keys[(size_t)(j - cap) * stride + opl];
       if (v > m1) { m2 = m1; m1 = v; i1 = j; }
       else if (v > m2) m2 = v;
     }
@@ -684,8 +685,8 @@ __device__ __attribute__((noinline)) void full_list_insert(unsigned long long pe
     if (lane == 0) {
       unsigned long long largest = m1;
       if (okey < m1) {
-        if (i1 < cap) lds_keys[(size_t)i1 * 64 + opl] = okey;
-        else spill_keys[(size_t)(i1 - cap) * 64 + opl] = okey;
+        if (i1 < cap) lds_keys[(size_t)i1 * stride + opl] = okey;
+        else spill_keys[(size_t)(i1 - cap) * stride + opl] = okey;
         largest = okey > m2 ? okey : m2;
       }
       thr[opl] = largest;
@@ -699,23 +700,33 @@ __device__ __attribute__((noinline)) void full_list_insert(unsigned long long pe
 // MASKS (fused mode, equal-sized meshes): the bin's face list comes from the face masks the prep kernel left behind
 // instead of a scan of all the mesh's face boxes: same test, same faces, same order -- 32 bytes per 256 faces to read
 // instead of 256 boxes.
-template <int MODE, bool BIGK, bool MASKS>
-__global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
+// G8 (fused mode): EIGHT waves per 16x16 bin, each owning 32 pixels (every second column, every fourth row) instead of
+// four waves of 64.  A wave's chain of dependent steps -- pair batches, sorts, shading rounds, all in proportion to its
+// pixels -- is half as long, and a launch has twice as many waves to fill the machine with (the reference's own 64x64
+// training images are 2048 waves of 64 pixels for 4096 resident slots; at the headline size the kernel lasted as long
+// as its heaviest bins' chains).  Workgroups of 512 threads, two per CU: the same 16 waves per CU.  Lanes 32..63 of
+// such a wave own no pixel; they work wherever work is dealt over the lanes (pairs, items, sorting networks).
+template <int MODE, bool BIGK, bool MASKS, bool G8 = false>
+__global__ void __launch_bounds__(G8 ? 512 : 256, 4) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BW = 16, BH = 16, WPB = 4;
-  // LDS carve (kRasterFixedLds bytes, then the keys):
-  //   [bin list 2048 u16][wave counts 16 i32][per wave: 72 i32 pair prefix (reused as the item prefix of the fused
-  //   tail)][per wave: 64 u32 pair decode info][per wave: 64 i32 list lengths][per wave: 64 u64 hide keys]
-  //   [staged bbox 2x64 float4][staged records 2x320 float4][keys]
+  static_assert(!G8 || MODE == 2, "eight-wave bins are the fused mode's");
+  constexpr int BW = 16, BH = 16, WPB = G8 ? 8 : 4;
+  constexpr int GP = 256 / WPB;     // pixels per wave group
+  constexpr int ROWS = GP / 8;      // pixel rows of a group (8 columns each)
+  constexpr int NT = 64 * WPB;      // threads per workgroup
+  // LDS carve (raster_fixed_lds() bytes, then the keys):
+  //   [bin list 2048 u16][wave counts 4 x WPB i32][per wave: 96 i32 pair prefix + marks (reused as the item prefix of
+  //   the fused tail)][per wave: 64 u32 pair decode info][per wave: 64 i32 list lengths][per wave: 64 u64 hide keys]
+  //   [staged bbox 2x64 float4][staged records 2x320 float4][G8: 512 float4 more for the tail's result slots][keys]
   uint16_t* s_bin = reinterpret_cast<uint16_t*>(smem);
   int32_t* s_wcnt = reinterpret_cast<int32_t*>(s_bin + kBinCap);
-  int32_t* s_fpre_all = s_wcnt + 16;
-  uint32_t* s_finfo_all = reinterpret_cast<uint32_t*>(s_fpre_all + 4 * kPreStride);
-  int32_t* s_cnt_all = reinterpret_cast<int32_t*>(s_finfo_all + 4 * 64);
-  unsigned long long* s_hide_all = reinterpret_cast<unsigned long long*>(s_cnt_all + 4 * 64);
-  float4* s_bb = reinterpret_cast<float4*>(s_hide_all + 4 * 64);
+  int32_t* s_fpre_all = s_wcnt + 4 * WPB;
+  uint32_t* s_finfo_all = reinterpret_cast<uint32_t*>(s_fpre_all + WPB * kPreStride);
+  int32_t* s_cnt_all = reinterpret_cast<int32_t*>(s_finfo_all + WPB * 64);
+  unsigned long long* s_hide_all = reinterpret_cast<unsigned long long*>(s_cnt_all + WPB * 64);
+  float4* s_bb = reinterpret_cast<float4*>(s_hide_all + WPB * 64);
   float4* s_rec = s_bb + 2 * kSub;
-  unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(s_rec + 2 * kSub * 5);
+  unsigned long long* s_keys_all = reinterpret_cast<unsigned long long*>(s_rec + 2 * kSub * 5 + (G8 ? 512 : 0));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // workgroup schedule: heaviest bins first (k_bin_order)
@@ -729,10 +740,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   if (MODE == 2 && (sched & kEmptyBin)) {
     // a bin the schedule flagged empty (no face box reaches it; half the bins of a batch of centred objects): its
     // pixels are background and its layer counts zero -- written straight away, none of the set-up below
-    const int ex = bx * BW + (wave & 1) + 2 * (lane & 7), ey = by * BH + (wave >> 1) + 2 * (lane >> 3);
-    if (bx * BW + (wave & 1) < W && by * BH + (wave >> 1) < H) {
-      const int64_t etile = (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
-      P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + etile * 64 + lane] = 0;
+    const int ex = bx * BW + (wave & 1) + 2 * (lane & 7), ey = by * BH + (wave >> 1) + (G8 ? 4 : 2) * (lane >> 3);
+    if (bx * BW + (wave & 1) < W && by * BH + (wave >> 1) < H && lane < GP) {
+      const int64_t etile = (((int64_t)n * P.nby + by) * P.nbx + bx) * WPB + wave;
+      P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + etile * GP + lane] = 0;
       if (ex < W && ey < H) {
         const int64_t hw = (int64_t)H * W;
         float* img = P.image + (int64_t)n * 4 * hw + (int64_t)ey * W + ex;
@@ -755,25 +766,28 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   // this wave's 64 pixels.  MODE 1 (tile lists): the 8x8 tile (wave & 1, wave >> 1) of the bin.  Otherwise every
   // second column / row of the bin starting at (wave & 1, wave >> 1): the four waves of a workgroup then see almost
   // the same load whatever the bin holds (a silhouette through one corner would otherwise leave three waves idle).
-  const int xs = (MODE == 1) ? 1 : 2;                 // pixel stride inside the wave
+  // (G8: every second column and every FOURTH row from (wave & 1, wave >> 1), 8 columns x 4 rows)
+  const int xs = (MODE == 1) ? 1 : 2;                 // pixel stride inside the wave: columns
+  const int ys = (MODE == 1) ? 1 : (G8 ? 4 : 2);      //                               rows
   const int tx0 = bx0 + (wave & 1) * (MODE == 1 ? kTile : 1), ty0 = by0 + (wave >> 1) * (MODE == 1 ? kTile : 1);
   const bool tile_live = (tx0 < W) && (ty0 < H);
-  const int tx1 = min(W, tx0 + xs * (kTile - 1) + 1) - 1, ty1 = min(H, ty0 + xs * (kTile - 1) + 1) - 1;
+  const int tx1 = min(W, tx0 + xs * (kTile - 1) + 1) - 1, ty1 = min(H, ty0 + ys * (ROWS - 1) + 1) - 1;
   const float txc_hi = pix_to_ndc(W - 1 - tx0, ax_x), txc_lo = pix_to_ndc(W - 1 - max(tx1, tx0), ax_x);
   const float tyc_hi = pix_to_ndc(H - 1 - ty0, ax_y), tyc_lo = pix_to_ndc(H - 1 - max(ty1, ty0), ax_y);
 
   // this lane's pixel
-  const int x = tx0 + xs * (lane & 7), y = ty0 + xs * (lane >> 3);
-  const bool pix_live = (x < W) && (y < H);
+  const int x = tx0 + xs * (lane & 7), y = ty0 + ys * (lane >> 3);
+  const bool pix_live = (x < W) && (y < H) && (lane < GP);
   const float px = pix_to_ndc(W - 1 - x, ax_x), py = pix_to_ndc(H - 1 - y, ax_y);
 
   // index of this wave's pixel group in layers / spill / tile lists
   const int64_t tile_id = (MODE == 1) ? ((int64_t)n * ((H + 7) / 8) + (ty0 >> 3)) * ((W + 7) / 8) + (tx0 >> 3)
-                                      : (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
+                                      : (((int64_t)n * P.nby + by) * P.nbx + bx) * WPB + wave;
   KeyList keys;
   keys.cap = P.cap;
-  keys.lds = s_keys_all + (size_t)wave * P.cap * 64 + lane;
-  keys.spill = P.spill + (tile_live ? tile_id : 0) * (int64_t)(KL - P.cap) * 64 + lane;
+  keys.stride = GP;
+  keys.lds = s_keys_all + (size_t)wave * P.cap * GP + (lane & (GP - 1));
+  keys.spill = P.spill + (tile_live ? tile_id : 0) * (int64_t)(KL - P.cap) * GP + (lane & (GP - 1));
   int cnt = 0;       // entries in this lane's list
   // BIGK, list full: the two largest entries found by the last scan of the list (full_known = how many of them still
   // hold: 2 after a scan, 1 after one replacement, 0 = scan again); any compaction or append resets it
@@ -798,23 +812,23 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   uint32_t* s_finfo = s_finfo_all + wave * 64;
   int32_t* s_cnt = s_cnt_all + wave * 64;
   unsigned long long* s_hide = s_hide_all + wave * 64;
-  unsigned long long* const lds_keys = s_keys_all + (size_t)wave * P.cap * 64;
-  unsigned long long* const spill_keys = P.spill + (tile_live ? tile_id : 0) * (int64_t)(KL - P.cap) * 64;
+  unsigned long long* const lds_keys = s_keys_all + (size_t)wave * P.cap * GP;
+  unsigned long long* const spill_keys = P.spill + (tile_live ? tile_id : 0) * (int64_t)(KL - P.cap) * GP;
   float pxc[8], pyc[8];                // the tile's 8 column / 8 row centres (wave-uniform)
   unsigned livecols = 0, liverows = 0;
   // a full list's largest key (all ones while the list is not full): candidates that do not beat it are dropped
   // without a look at the list
-  unsigned long long* const thr_keys = (MODE == 2) ? P.full_thr + (tile_live ? tile_id : 0) * 64 : nullptr;
+  unsigned long long* const thr_keys = (MODE == 2) ? P.full_thr + (tile_live ? tile_id : 0) * GP : nullptr;
   if (MODE == 2) {
     s_cnt[lane] = 0;
     s_hide[lane] = ~0ull;
-    if (tile_live) thr_keys[lane] = ~0ull;
+    if (tile_live && lane < GP) thr_keys[lane] = ~0ull;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       pxc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), j));
       pyc[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), j * 8));
       livecols |= (tx0 + xs * j < W) ? (1u << j) : 0u;
-      liverows |= (ty0 + xs * j < H) ? (1u << j) : 0u;
+      liverows |= (j < ROWS && ty0 + ys * j < H) ? (1u << j) : 0u;
     }
   }
 
@@ -830,7 +844,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     //      half: the fused blend can then skip most of the far side of a closed mesh (z_hide below).  Order never
     //      changes results -- selection is by (depth, face).
     const int fbase = (int32_t)f0 + rbase;  // packed index of the round's first face: face = fbase + s_bin[i]
-    const int per = ((min(nf - rbase, kBinCap) + 255) >> 8) << 6;  // faces per wave (multiple of 64)
+    const int per = ((min(nf - rbase, kBinCap) + NT - 1) / NT) << 6;  // faces per wave (multiple of 64)
     const int wbase = rbase + wave * per;
     float zv[kScanQ];
     unsigned long long pm[kScanQ];
@@ -882,8 +896,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     }
     if (lane == 0) {
       s_wcnt[wave] = wc;
-      s_wcnt[8 + wave] = __float_as_int(zlo);
-      s_wcnt[12 + wave] = __float_as_int(zhi);
+      s_wcnt[2 * WPB + wave] = __float_as_int(zlo);
+      s_wcnt[3 * WPB + wave] = __float_as_int(zhi);
     }
     __syncthreads();
     float zmid = __builtin_inff();
@@ -891,8 +905,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       float a = __builtin_inff(), b2 = -__builtin_inff();
 #pragma unroll
       for (int w = 0; w < WPB; ++w) {
-        a = fminf(a, __int_as_float(s_wcnt[8 + w]));
-        b2 = fmaxf(b2, __int_as_float(s_wcnt[12 + w]));
+        a = fminf(a, __int_as_float(s_wcnt[2 * WPB + w]));
+        b2 = fmaxf(b2, __int_as_float(s_wcnt[3 * WPB + w]));
       }
       zmid = 0.5f * (a + b2);
     }
@@ -903,12 +917,12 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       nm[q] = (MODE == 2) ? __ballot(((pm[q] >> lane) & 1ull) && zv[q] <= zmid) : pm[q];
       wn += __popcll(nm[q]);
     }
-    if (lane == 0) s_wcnt[4 + wave] = wn;
+    if (lane == 0) s_wcnt[WPB + wave] = wn;
     __syncthreads();
     int list_n = 0, near_n = 0, pre_all = 0, pre_near = 0;
 #pragma unroll
     for (int w = 0; w < WPB; ++w) {
-      const int c = s_wcnt[w], cn = s_wcnt[4 + w];
+      const int c = s_wcnt[w], cn = s_wcnt[WPB + w];
       pre_all += (w < wave) ? c : 0;
       pre_near += (w < wave) ? cn : 0;
       list_n += c;
@@ -938,7 +952,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       const int cntc = min(kSub, list_n - c * kSub);
       if (tid < cntc) r_bb = P.bbox[fbase + s_bin[c * kSub + tid]];
       if (tid < cntc * 5) r_r0 = P.rec[5 * (size_t)(fbase + s_bin[c * kSub + tid / 5]) + tid % 5];
-      if (tid + 256 < cntc * 5) r_r1 = P.rec[5 * (size_t)(fbase + s_bin[c * kSub + (tid + 256) / 5]) + (tid + 256) % 5];
+      if (NT < kSub * 5 && tid + 256 < cntc * 5)
+        r_r1 = P.rec[5 * (size_t)(fbase + s_bin[c * kSub + (tid + 256) / 5]) + (tid + 256) % 5];
     };
     auto stage_write = [&](int c) {
       const int cntc = min(kSub, list_n - c * kSub);
@@ -946,7 +961,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       float4* rc = s_rec + (c & 1) * kSub * 5;
       if (tid < cntc) bb[tid] = r_bb;
       if (tid < cntc * 5) rc[tid] = r_r0;
-      if (tid + 256 < cntc * 5) rc[tid + 256] = r_r1;
+      if (NT < kSub * 5 && tid + 256 < cntc * 5) rc[tid + 256] = r_r1;
     };
     stage_load(0);
     stage_write(0);
@@ -1157,8 +1172,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                     if (key <= hk) {
                       const int slot = atomicAdd(&s_cnt[pl], 1);
                       if (slot < KL) {
-                        if (slot < P.cap) lds_keys[(size_t)slot * 64 + pl] = key;
-                        else spill_keys[(size_t)(slot - P.cap) * 64 + pl] = key;
+                        if (slot < P.cap) lds_keys[(size_t)slot * GP + pl] = key;
+                        else spill_keys[(size_t)(slot - P.cap) * GP + pl] = key;
                       } else {
                         atomicSub(&s_cnt[pl], 1);  // the list is full
                         if (key < thr_keys[pl]) over_key = key;
@@ -1171,7 +1186,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
                 const unsigned long long pending = __ballot(over_key != ~0ull);
                 if (pending) {
                   wave_lds_handoff();  // the lists it scans were appended to by any lane
-                  full_list_insert(pending, over_key, pl, lds_keys, spill_keys, thr_keys, P.cap, KL);
+                  full_list_insert(pending, over_key, pl, lds_keys, spill_keys, thr_keys, P.cap, KL, GP);
                   wave_lds_handoff();
                 }
               }
@@ -1301,7 +1316,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           const unsigned long long hk = __shfl(hide_key, myl, 64);
           const int myn = have ? nl : 0;
           unsigned long long v = ~0ull;
-          if (j < myn) v = (j < P.cap) ? lds_base[(size_t)j * 64 + myl] : spill_base[(size_t)(j - P.cap) * 64 + myl];
+          if (j < myn) v = (j < P.cap) ? lds_base[(size_t)j * GP + myl] : spill_base[(size_t)(j - P.cap) * GP + myl];
           if (v > hk) v = ~0ull;  // hidden
 #pragma unroll
           for (int k = 2; k <= Wd; k <<= 1)
@@ -1314,8 +1329,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           const unsigned long long live = __ballot(v != ~0ull) >> (sub * Wd);
           const int kept = __popcll(Wd == 64 ? live : (live & ((1ull << (Wd & 63)) - 1ull)));
           if (j < kept) {
-            if (j < P.cap) lds_base[(size_t)j * 64 + myl] = v;
-            else spill_base[(size_t)(j - P.cap) * 64 + myl] = v;
+            if (j < P.cap) lds_base[(size_t)j * GP + myl] = v;
+            else spill_base[(size_t)(j - P.cap) * GP + myl] = v;
           }
           if (have && j == 0) s_cnt[myl] = kept;  // the list's new length, picked up by its pixel below
         }
@@ -1341,7 +1356,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           for (int r2 = 0; r2 < 2; ++r2) {
             const int e = lane + 64 * r2;
             v[r2] = ~0ull;
-            if (e < nl) v[r2] = (e < P.cap) ? lds_base[(size_t)e * 64 + l] : spill_base[(size_t)(e - P.cap) * 64 + l];
+            if (e < nl) v[r2] = (e < P.cap) ? lds_base[(size_t)e * GP + l] : spill_base[(size_t)(e - P.cap) * GP + l];
             if (v[r2] > hk) v[r2] = ~0ull;  // hidden
           }
 #pragma unroll
@@ -1366,8 +1381,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
           for (int r2 = 0; r2 < 2; ++r2) {
             const int e = lane + 64 * r2;
             if (v[r2] != ~0ull) {  // sorted: the kept entries come first
-              if (e < P.cap) lds_base[(size_t)e * 64 + l] = v[r2];
-              else spill_base[(size_t)(e - P.cap) * 64 + l] = v[r2];
+              if (e < P.cap) lds_base[(size_t)e * GP + l] = v[r2];
+              else spill_base[(size_t)(e - P.cap) * GP + l] = v[r2];
             }
           }
           const int kept = __popcll(__ballot(v[0] != ~0ull)) + __popcll(__ballot(v[1] != ~0ull));
@@ -1388,9 +1403,10 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     wave_lds_handoff();
     // the staging buffers are dead once the fine step is over (every wave is past its last barrier): this wave's
     // slice of them carries the batch's (alpha, r, g, b) from the lanes that computed them to the pixels' owners
-    float4* s_res = s_rec + wave * 160;                      // 128 float4: (alpha, r, g, b) of a round's items
+    // (eight waves need 8 x 160 float4: the staged boxes, the staged records and the 512 float4 behind them)
+    float4* s_res = (G8 ? s_bb : s_rec) + wave * 160;        // 128 float4: (alpha, r, g, b) of a round's items
     float* s_occ = reinterpret_cast<float*>(s_res + 128);    // 128 floats: transmittance in front of each of them
-    int4* lay_rows = reinterpret_cast<int4*>(P.layers + tile_id * (int64_t)K * 64 * kRowWords);  // [item][2 x int4]
+    int4* lay_rows = reinterpret_cast<int4*>(P.layers + tile_id * (int64_t)K * GP * kRowWords);  // [item][2 x int4]
     float occ = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
     // One round takes 64 U items, U per lane.  The item phase is a chain of dependent memory round trips (key ->
     // record + UVs -> texels) with little arithmetic in between, so two items per lane are walked through it side by
@@ -1417,8 +1433,8 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        unsigned long long key = lds_base[(size_t)min(ik[u], P.cap - 1) * 64 + il[u]];
-        if (ik[u] >= P.cap) key = spill_base[(size_t)(ik[u] - P.cap) * 64 + il[u]];
+        unsigned long long key = lds_base[(size_t)min(ik[u], P.cap - 1) * GP + il[u]];
+        if (ik[u] >= P.cap) key = spill_base[(size_t)(ik[u] - P.cap) * GP + il[u]];
         ifid[u] = key_face(key);
       }
       Face fc[U];
@@ -1435,7 +1451,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const float qx = pix_to_ndc(W - 1 - (tx0 + xs * (il[u] & 7)), ax_x);
-        const float qy = pix_to_ndc(H - 1 - (ty0 + xs * (il[u] >> 3)), ax_y);
+        const float qy = pix_to_ndc(H - 1 - (ty0 + ys * (il[u] >> 3)), ax_y);
         Eval ev;
         eval_face(fc[u], qx, qy, P.blur, P.clip != 0, ev);
         va[u] = layer_alpha(ev.sd, true, P.sigma, P.mode);
@@ -1476,7 +1492,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
     int base = 0;
     for (; base + 64 < total; base += 128) round(std::integral_constant<int, 2>{}, base);
     if (base < total) round(std::integral_constant<int, 1>{}, base);
-    P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] = m;  // per-pixel layer count
+    if (lane < GP) P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * GP + lane] = m;  // per-pixel layer count
     if (pix_live) {
       const int64_t hw = (int64_t)H * W;
       float* img = P.image + (int64_t)n * 4 * hw + (int64_t)y * W + x;
@@ -1520,7 +1536,7 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
   // padding: for every pixel of the tile the slots [nout, K) are written by lanes that sweep k (contiguous stores)
   for (int p = 0; p < 64; ++p) {
     const int pcnt = __builtin_amdgcn_readlane(nout, p);
-    const int qx = tx0 + xs * (p & 7), qy = ty0 + xs * (p >> 3);
+    const int qx = tx0 + xs * (p & 7), qy = ty0 + ys * (p >> 3);
     if (qx >= W || qy >= H) continue;
     const int64_t qbase = (((int64_t)n * H + qy) * W + qx) * K;
     for (int k = pcnt + lane; k < K; k += 64) {
@@ -1536,9 +1552,28 @@ __global__ void __launch_bounds__(256, 4) k_raster(const RasterParams P) {
 // 64-pixel groups (one per wave) of an image: 4 per 16x16 bin
 size_t wave_groups(int H, int W) { return (size_t)((H + 15) / 16) * ((W + 15) / 16) * 4; }
 
-constexpr size_t kRasterFixedLds = (size_t)kBinCap * 2 + 64 + 4 * kPreStride * 4 + 4 * 64 * 4 + 4 * 64 * 4 + 4 * 64 * 8 +
-                                   2 * kSub * 16 + 2 * kSub * 5 * 16;
+// LDS of k_raster before the key lists (see its carve); wpb = waves per bin (4, or 8 in the G8 build)
+constexpr size_t raster_fixed_lds(int wpb) {
+  return (size_t)kBinCap * 2 + (size_t)wpb * 16 + (size_t)wpb * kPreStride * 4 + (size_t)wpb * 64 * 4 +
+         (size_t)wpb * 64 * 4 + (size_t)wpb * 64 * 8 + 2 * kSub * 16 + 2 * kSub * 5 * 16 + (wpb == 8 ? 512 * 16 : 0);
+}
 
+// Does the fused path run eight waves of 32 pixels per bin (k_raster<2, ., ., true>) rather than four of 64?  A pure
+// function of the call's sizes: the forward and the backward of a step must agree on the layout of `layers`.
+#ifndef UR_FUSED_G8
+#define UR_FUSED_G8 1
+#endif
+// Measured (profiles/r03_ab_g8.txt, graph replay): it pays when the launch is too small to fill the chip with four
+// waves per bin -- the reference's own training size, 32 images of 64x64: 2048 waves for 4096 resident slots, +16 % --
+// and costs 13-20 % where the machine is full anyway (twice the per-chunk rectangle work, half-empty lane = pixel
+// steps).  So: eight waves while all bins of the launch, four waves each, would not fill the resident wave slots.
+constexpr int kResidentWaves = 256 * 16;  // MI355X: 256 CUs x 16 waves at this kernel's register budget
+bool fused_g8(int N, int H, int W, int K) {
+  (void)K;
+  if (UR_FUSED_G8 == 0) return false;
+  if (UR_FUSED_G8 == 2) return true;  // (build switch for A/B timing: always)
+  return (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16) * 4 <= kResidentWaves;
+}
 // K-list slots per pixel kept in LDS (the rest spills to global memory): what fits four workgroups per CU (40 KB
 // each).  Round 1 traded occupancy for LDS residency on dense meshes (three / two workgroups per CU), because lists
 // leaving LDS made the in-loop compactions and the lane = pixel full-list route dear; with both gone (appends beyond
@@ -1556,11 +1591,13 @@ bool render_bwd_dense(int64_t total_faces, int N, int H, int W, int Ht, int Wt) 
 
 // The fragment-writing build (lane = pixel, keep-the-K-smallest in place) still prefers its lists in LDS on dense
 // meshes: three workgroups per CU from 0.2 faces per pixel, two when K > 64 as well.
-int raster_cap(int64_t total_faces, int N, int H, int W, int K, bool fused = true) {
+int raster_cap(int64_t total_faces, int N, int H, int W, int K, bool fused = true, bool g8 = false) {
   const int KL = list_cap(K);
   const double density = (double)total_faces / (double)(N > 0 ? N : 1) / ((double)H * (double)W);
-  const size_t budget = (fused || density < 0.2) ? (size_t)kLdsBudget : (K > 64 ? (size_t)80 * 1024 : (size_t)52 * 1024);
-  const int fit = (int)((budget - kRasterFixedLds) / (4 * 64 * 8));
+  // (G8: two workgroups of eight waves per CU, 80 KB each; a slot of all 256 pixels of a bin is 2 KB either way)
+  const size_t budget = g8 ? (size_t)2 * kLdsBudget
+                           : ((fused || density < 0.2) ? (size_t)kLdsBudget : (K > 64 ? (size_t)80 * 1024 : (size_t)52 * 1024));
+  const int fit = (int)((budget - raster_fixed_lds(g8 ? 8 : 4)) / (4 * 64 * 8));
   return KL < fit ? KL : fit;
 }
 
@@ -1572,29 +1609,33 @@ size_t raster_spill_bytes(int64_t total_faces, int N, int H, int W, int K) {
   return over <= 0 ? 0 : (size_t)N * wave_groups(H, W) * (size_t)over * 64 * 8;
 }
 
-template <int MODE, bool BIGK, bool MASKS> int launch_raster_k(RasterParams P, hipStream_t st) {
+template <int MODE, bool BIGK, bool MASKS, bool G8 = false> int launch_raster_k(RasterParams P, hipStream_t st) {
   P.nbx = (P.W + 15) / 16;
   P.nby = (P.H + 15) / 16;
   P.KL = list_cap(P.K);
-  P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K, MODE == 2);
-  const size_t lds = kRasterFixedLds + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
+  P.cap = (MODE == 1) ? 1 : raster_cap(P.total_faces, P.N, P.H, P.W, P.K, MODE == 2, G8);
+  // the workspace's spill area is sized for the four-wave build's cap: the cap in use must not be smaller
+  if (MODE != 1 && P.cap < raster_cap(P.total_faces, P.N, P.H, P.W, P.K)) return fail(UR_ERR_WORKSPACE, "K-list cap");
+  const size_t lds = raster_fixed_lds(G8 ? 8 : 4) + (MODE == 1 ? 0 : (size_t)4 * P.cap * 64 * 8);
   static LdsSlot lds_slot;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE, BIGK, MASKS>), lds, lds_slot)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_raster<MODE, BIGK, MASKS, G8>), lds, lds_slot)) return rc;
   const int64_t blocks = (int64_t)P.N * P.nbx * P.nby;
   if (blocks > (int64_t)kBinIndex) return fail(UR_ERR_INVALID_ARG, "grid too large");  // bit 30 of an entry = kEmptyBin
   {
     ProfScope prof(MODE == 2 ? UR_PROFILE_RASTER_FWD : UR_PROFILE_OTHER, st);
-    hipLaunchKernelGGL((k_raster<MODE, BIGK, MASKS>), dim3((unsigned)blocks), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((k_raster<MODE, BIGK, MASKS, G8>), dim3((unsigned)blocks), dim3(G8 ? 512 : 256), lds, st, P);
   }
   return check_launch("k_raster");
 }
 
 template <int MODE> int launch_raster(RasterParams P, hipStream_t st) {
   if constexpr (MODE == 2) {
-    if (P.masks) {
-      if (list_cap(P.K) > 64) return launch_raster_k<MODE, true, true>(P, st);
-      return launch_raster_k<MODE, false, true>(P, st);
+    const bool big = list_cap(P.K) > 64;
+    if (fused_g8(P.N, P.H, P.W, P.K)) {
+      if (P.masks) return big ? launch_raster_k<2, true, true, true>(P, st) : launch_raster_k<2, false, true, true>(P, st);
+      return big ? launch_raster_k<2, true, false, true>(P, st) : launch_raster_k<2, false, false, true>(P, st);
     }
+    if (P.masks) return big ? launch_raster_k<2, true, true>(P, st) : launch_raster_k<2, false, true>(P, st);
   }
   P.masks = nullptr;
   if (MODE != 1 && list_cap(P.K) > 64) return launch_raster_k<MODE, true, false>(P, st);
@@ -1852,8 +1893,16 @@ __device__ __forceinline__ int lds_claim(int* tags, int h, int key, int slots) {
   return -1;
 }
 
-template <int kFaceSlots, int kTexCols>
-__global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
+// G8: the forward ran eight waves of 32 pixels per bin (k_raster<2, ., ., true>).  W8 = false: the four waves here take
+// two of its pixel groups each, one after the other (wave w: groups w and w + 4); W8 = true: eight waves, one group each
+// (workgroups of 512 threads).
+template <int kFaceSlots, int kTexCols, bool G8, bool W8 = false>
+__global__ void __launch_bounds__(W8 ? 512 : 256) k_render_bwd(const RasterParams P) {
+  static_assert(G8 || !W8, "eight waves need eight groups");
+  constexpr int WPB = G8 ? 8 : 4;   // pixel groups per bin
+  constexpr int GP = 256 / WPB;     // pixels per group
+  constexpr int NT = W8 ? 512 : 256;
+  constexpr int WAVES = NT / 64;
   constexpr int kTexSlots = 16 * kTexCols;
   __shared__ int s_ftag[kFaceSlots];
   __shared__ int s_ttag[kTexSlots];
@@ -1879,29 +1928,43 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
   if (sched & kEmptyBin) return;  // no face box reaches the bin: the forward left no rows
   const int b = item - n * (P.nbx * P.nby);
   const int by = b / P.nbx, bx = b - by * P.nbx;
-  const int tx0 = bx * 16 + (wave & 1), ty0 = by * 16 + (wave >> 1);
-  const bool tile_live = (tx0 < W) && (ty0 < H);
-  const int x = tx0 + 2 * (lane & 7), y = ty0 + 2 * (lane >> 3);
-  const bool live = (x < W) && (y < H);
-  const int64_t tile_id = (((int64_t)n * P.nby + by) * P.nbx + bx) * 4 + wave;
-  // the group's layer rows (layout: kRowWords) and one float of scratch per row
-  const int4* lay_rows = reinterpret_cast<const int4*>(P.layers + (tile_live ? tile_id : 0) * (int64_t)K * 64 * kRowWords);
-  float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * 64;  // [item]: dL/dalpha of the layer
   float* gmap = P.gmaps ? P.gmaps + (int64_t)mesh_of(P, n) * P.Ht * P.Wt * 3 : nullptr;
-
-  // this pixel's layer count (left by the forward); the group's rows are in pixel-major item order: this pixel's
-  // layers are rows [pre, pre + m)
-  const int m = (tile_live && live) ? P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + tile_id * 64 + lane] : 0;
-  const int incl = wave_scan_add(m);
-  const int total = __builtin_amdgcn_readlane(incl, 63);
-  if (!__syncthreads_or(total > 0)) return;  // nothing rendered in this bin
-  const int lo = 0, hi = total;
-  for (int i = tid; i < kFaceSlots; i += 256) s_ftag[i] = -1;
-  for (int i = tid; i < kFaceSlots * kFaceStride; i += 256) s_fval[i] = 0.0;
-  for (int i = tid; i < kTexSlots; i += 256) s_ttag[i] = -1;
-  for (int i = tid; i < kTexSlots * 3; i += 256) s_tval[i] = 0.0;
+  // this wave's pixel groups: per-pixel layer counts (left by the forward) of each.  A group's rows are in pixel-major
+  // item order: the layers of a pixel are rows [pre, pre + m).
+  constexpr int NG = WPB / WAVES;
+  int m_g[NG], any_rows = 0;
+#pragma unroll
+  for (int gs = 0; gs < NG; ++gs) {
+    const int grp = wave + WAVES * gs;
+    const int gx0 = bx * 16 + (grp & 1), gy0 = by * 16 + (grp >> 1);
+    const int gx = gx0 + 2 * (lane & 7), gy = gy0 + (G8 ? 4 : 2) * (lane >> 3);
+    const bool glive = (gx0 < W) && (gy0 < H) && (gx < W) && (gy < H) && (lane < GP);
+    const int64_t gid = (((int64_t)n * P.nby + by) * P.nbx + bx) * WPB + grp;
+    m_g[gs] = glive ? P.layers[layer_counts_offset(P.N, P.nbx, P.nby, K) + gid * GP + lane] : 0;
+    any_rows |= m_g[gs];
+  }
+  if (!__syncthreads_or(any_rows > 0)) return;  // nothing rendered in this bin
+  for (int i = tid; i < kFaceSlots; i += NT) s_ftag[i] = -1;
+  for (int i = tid; i < kFaceSlots * kFaceStride; i += NT) s_fval[i] = 0.0;
+  for (int i = tid; i < kTexSlots; i += NT) s_ttag[i] = -1;
+  for (int i = tid; i < kTexSlots * 3; i += NT) s_tval[i] = 0.0;
   __syncthreads();
 
+#pragma unroll 1
+  for (int gs = 0; gs < NG; ++gs) {
+  const int grp = wave + WAVES * gs;
+  const int tx0 = bx * 16 + (grp & 1), ty0 = by * 16 + (grp >> 1);
+  const bool tile_live = (tx0 < W) && (ty0 < H);
+  const int x = tx0 + 2 * (lane & 7), y = ty0 + (G8 ? 4 : 2) * (lane >> 3);
+  const bool live = (x < W) && (y < H) && (lane < GP);
+  const int64_t tile_id = (((int64_t)n * P.nby + by) * P.nbx + bx) * WPB + grp;
+  // the group's layer rows (layout: kRowWords) and one float of scratch per row
+  const int4* lay_rows = reinterpret_cast<const int4*>(P.layers + (tile_live ? tile_id : 0) * (int64_t)K * GP * kRowWords);
+  float* scr_tile = P.scratch + (tile_live ? tile_id : 0) * (int64_t)K * GP;  // [item]: dL/dalpha of the layer
+  const int m = (NG > 1 && gs > 0) ? m_g[NG - 1] : m_g[0];
+  const int incl = wave_scan_add(m);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int lo = 0, hi = total;
   if (hi > lo) {
     const int64_t hw = (int64_t)H * W;
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
@@ -2080,17 +2143,18 @@ __global__ void __launch_bounds__(256) k_render_bwd(const RasterParams P) {
       }
     }
   }
+  }  // pixel groups of this wave
 
   __syncthreads();
   if (P.gfv)
-    for (int i = tid; i < kFaceSlots * 6; i += 256) {
+    for (int i = tid; i < kFaceSlots * 6; i += NT) {
       const int slot = i / 6, c = i - slot * 6;
       const int tag = s_ftag[slot];
       const float v = (float)s_fval[slot * kFaceStride + c];
       if (tag >= 0 && v != 0.0f) atomicAdd(face_sum(tag, c), v);
     }
   if (gmap)
-    for (int i = tid; i < kTexSlots * 3; i += 256) {
+    for (int i = tid; i < kTexSlots * 3; i += NT) {
       const int slot = i / 3, c = i - slot * 3;
       const int tag = s_ttag[slot];
       const float v = (float)s_tval[i];
@@ -3119,10 +3183,23 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
   if (blocks > (int64_t)kBinIndex) return fail(UR_ERR_INVALID_ARG, "grid too large");
   {
     ProfScope prof(UR_PROFILE_RENDER_BWD, (hipStream_t)stream);
-    if (render_bwd_dense(total_faces, N, H, W, Ht, Wt))
-      hipLaunchKernelGGL((k_render_bwd<512, 16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    const bool dense = render_bwd_dense(total_faces, N, H, W, Ht, Wt), g8 = fused_g8(N, H, W, K);
+#ifndef UR_BWD_W8
+#define UR_BWD_W8 1  // (eight-wave bins are small launches: one wave per group gave the backward 39 -> 33 us at 32 x 64x64)
+#endif
+    if (g8 && UR_BWD_W8) {
+      if (dense)
+        hipLaunchKernelGGL((k_render_bwd<512, 16, true, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, P);
+      else
+        hipLaunchKernelGGL((k_render_bwd<256, 32, true, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, P);
+    } else if (dense && g8)
+      hipLaunchKernelGGL((k_render_bwd<512, 16, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    else if (dense)
+      hipLaunchKernelGGL((k_render_bwd<512, 16, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+    else if (g8)
+      hipLaunchKernelGGL((k_render_bwd<256, 32, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
     else
-      hipLaunchKernelGGL((k_render_bwd<256, 32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+      hipLaunchKernelGGL((k_render_bwd<256, 32, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
   }
   return check_launch("k_render_bwd");
 }
@@ -3201,15 +3278,19 @@ int ur_render_meshes_forward(const float* verts, const int64_t* faces, int64_t f
                        zero_grad_maps, (int)n_gmap);
     rc = check_launch("k_project_prep_mesh");
     if (rc) return rc;
+    // (the schedule is built even when every workgroup of the launch is resident from the start: heaviest-first also
+    // pairs heavy bins with light ones on a CU -- workgroup i and i + 256 share one -- and taking bins in index order
+    // instead cost the 32 x 64x64 forward 34 -> 43 us)
     if (parts >= kBinSumParts) {
       hipLaunchKernelGGL(k_bin_sum, dim3((unsigned)((nbins + 255) / 256), (unsigned)N), dim3(256), 0, st, binload, parts, nbins);
       rc = check_launch("k_bin_sum");
       if (rc) return rc;
       hipLaunchKernelGGL(k_bin_order, dim3(1), dim3(1024), 0, st, binload, N * nbins, order, 1, nbins, parts * nbins);
+      rc = check_launch("k_bin_order");
     } else {
       hipLaunchKernelGGL(k_bin_order, dim3(1), dim3(1024), 0, st, binload, N * nbins, order, parts, nbins, nbins);
+      rc = check_launch("k_bin_order");
     }
-    rc = check_launch("k_bin_order");
     if (rc) return rc;
   } else {
     // large meshes: the per-face kernels (a mesh spread over many workgroups, globally sorted schedule)
