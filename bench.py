@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 from unicorn_amd import dist as udist  # noqa: E402
 from unicorn_amd import native, synth  # noqa: E402
 from unicorn_amd.renderer import Renderer  # noqa: E402
-from unicorn_amd.structures import Meshes, TexturesUV  # noqa: E402
+from unicorn_amd.structures import Meshes, TexturesUV, repeat  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
 # VALU issue roof: 256 CUs x 4 SIMDs at the 2.4 GHz nominal shader clock (MI355X_MICROARCH.md), one wave64 VALU
@@ -74,6 +74,9 @@ WORKLOADS = {
     "C2_B32_64x64_K50_ico3": dict(B=32, level=3, img=64, K=50, tex=64),
     "C4b_B64_128x128_K50_ico4": dict(B=64, level=4, img=128, K=50, tex=64),
     "C2p_B192_64x64_K50_ico3": dict(B=192, level=3, img=64, K=50, tex=64),      # pose step of cfg2: 32 x 6 candidates
+    # the same pose step called the way unicorn.py:226-233 calls it: 32 meshes (detached), repeat(meshes, 6), 192
+    # poses; gradients to R and T only.  The tiling is an index (structures.repeat -> n_meshes of the C ABI), no copies.
+    "C2pt_B32x6_64x64_K50_ico3": dict(B=192, poses=6, level=3, img=64, K=50, tex=64, grads="R+T"),
     "C3_B32_64x64_K25_ico3": dict(B=32, level=3, img=64, K=25, tex=64),         # cfg3: faces_per_pixel 25
     "C3p_B192_64x64_K25_ico3": dict(B=192, level=3, img=64, K=25, tex=64),
     "C5_B16_256x256_K100_ico5": dict(B=16, level=5, img=256, K=100, tex=64),
@@ -167,8 +170,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time eager Python steps instead of replaying the step's "
                     "hipGraph (the eager rate is reported either way, as eager_images_per_s)")
-    ap.add_argument("--grads", default="verts+texture+R+T", help="which inputs require grad (ablation only; the "
-                    "reported metric uses the default = all of them)")
+    ap.add_argument("--grads", default=None, help="which inputs require grad, e.g. verts+texture+R+T (ablation only; "
+                    "the reported metric uses the workload's default = all of them, R+T for the tiled pose step)")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_own_ranks(a.gpus))
@@ -186,22 +189,28 @@ def main():
 
     cfg = WORKLOADS[a.workload]
     B, H, K = cfg["B"], cfg["img"], cfg["K"]
+    a.grads = a.grads or cfg.get("grads", "verts+texture+R+T")
+    poses = cfg.get("poses", 1)       # candidate poses per mesh (K-major tiling, utils/mesh.py:43-71)
+    M = B // poses                    # distinct meshes
     sc = synth.make_scene(B, level=cfg["level"], tex_size=cfg["tex"], seed=udist.shard_seed(0, rank), device=dev)
     F = sc["faces"].shape[0]
     rend = Renderer(H, cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=1e-4).to(dev)
     want = set(a.grads.split("+"))
-    verts = sc["verts"].requires_grad_("verts" in want)
-    maps = sc["maps"].requires_grad_("texture" in want)
+    verts = sc["verts"][:M].contiguous().requires_grad_("verts" in want)
+    maps = sc["maps"][:M].contiguous().requires_grad_("texture" in want)
     R = sc["R"].requires_grad_("R" in want)
     T = sc["T"].requires_grad_("T" in want)
-    fb, ub = sc["faces"][None].expand(B, -1, -1), sc["verts_uvs"][None].expand(B, -1, -1)
+    fb, ub = sc["faces"][None].expand(M, -1, -1), sc["verts_uvs"][None].expand(M, -1, -1)
     cot = torch.randn(B, 4, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+
+    def build_meshes():
+        meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))  # unicorn.py:262-266,283
+        return repeat(meshes, poses) if poses > 1 else meshes                      # unicorn.py:232
 
     def step():
         for t in (verts, maps, R, T):
             t.grad = None
-        meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))  # unicorn.py:262-266,283
-        img = rend(meshes, R, T)
+        img = rend(build_meshes(), R, T)
         img.backward(cot)
         return img
 
@@ -217,11 +226,10 @@ def main():
             from unicorn_amd.graphs import GraphedStep
 
             def body():
-                meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
-                img = rend(meshes, R, T)
+                img = rend(build_meshes(), R, T)
                 img.backward(cot)
                 return img
-            run = GraphedStep(body, grads_of=(verts, maps, R, T))
+            run = GraphedStep(body, grads_of=tuple(t for t in (verts, maps, R, T) if t.requires_grad))
             blocks, replay_local = udist.timed_blocks(run, a.steps, a.warmup, world, cuda=True)
             replay_elapsed, local_elapsed = udist.median_block(blocks, replay_local)
             elapsed = replay_elapsed
@@ -268,7 +276,8 @@ def main():
                        "reported": "median block", "ms_per_step_min": round(min(blocks) / a.steps * 1e3, 4),
                        "ms_per_step_max": round(max(blocks) / a.steps * 1e3, 4)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": a.workload, "batch_per_gpu": B, "image": [H, H], "faces_per_pixel": K,
+            "config": {"workload": a.workload, "batch_per_gpu": B, "meshes_per_gpu": M, "image": [H, H],
+                       "faces_per_pixel": K,
                        "faces_per_mesh": F, "texture": [cfg["tex"], cfg["tex"]], "sigma": 1e-4,
                        "grads": a.grads, "launch": launch},
             "eager_images_per_s": round(udist.job_throughput(B, a.steps, eager_elapsed, world), 2),

@@ -119,8 +119,13 @@ def main():
     rank, local, world = udist.env_world()
     if world > 1:
         udist.isolate_miopen_cache(rank)                  # before the first convolution: no shared kernel-cache locks
+    # rehearsal on a box with fewer GPUs than ranks (UNICORN_BENCH_BACKEND=gloo, as in bench.py): the ranks share the
+    # GPUs and meet over gloo; on a node every rank has its own GPU and DDP's all-reduce runs on RCCL ("nccl")
+    backend = os.environ.get("UNICORN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    udist.init("nccl")
+    udist.init(backend)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)                                  # same initial weights on every rank
     model = TinyUnicorn(a.img).to(dev)
@@ -134,7 +139,9 @@ def main():
     udist.fence(world, cuda=True)
     dt = udist.max_over_ranks(time.perf_counter() - t0, world, cuda=True)
     if rank == 0:
-        print(f"{world} GPU(s): {world * a.batch * a.steps / dt:.0f} images/s through the whole training step "
+        shared = world > torch.cuda.device_count()
+        print(f"{world} rank(s){' SHARING ' + str(torch.cuda.device_count()) + ' GPU(s) over ' + backend if shared else ''}: "
+              f"{world * a.batch * a.steps / dt:.0f} images/s through the whole training step "
               f"(encoder + renderer + DDP all-reduce), loss {losses[0]:.4f} -> {losses[-1]:.4f}")
     udist.finish(world)
 

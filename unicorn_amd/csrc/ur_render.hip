@@ -594,7 +594,10 @@ __device__ __forceinline__ const float* face_uv_row(const RasterParams& P, int n
 constexpr int kScanQ = 8;         // faces per lane per scan round
 constexpr int kBinCap = 256 * kScanQ;  // faces per scan round = bin-list entries (u16 offsets into the round)
 constexpr int kSub = 64;         // faces staged in LDS per fine step
-constexpr int kLdsBudget = 40960;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU (see raster_cap)
+#ifndef UR_LDS_BUDGET
+#define UR_LDS_BUDGET 40960
+#endif
+constexpr int kLdsBudget = UR_LDS_BUDGET;  // a quarter of the CU's 160 KB: four workgroups (16 waves) per CU (see raster_cap)
 constexpr int kPreStride = 96;   // ints per wave in the pair-prefix array: 65 prefix entries, then 64 byte marks
 
 // Capacity of a pixel's candidate list while faces are being collected.  The K nearest of all candidates are among the
@@ -707,7 +710,10 @@ __device__ __attribute__((noinline)) void full_list_insert(unsigned long long pe
 // as its heaviest bins' chains).  Workgroups of 512 threads, two per CU: the same 16 waves per CU.  Lanes 32..63 of
 // such a wave own no pixel; they work wherever work is dealt over the lanes (pairs, items, sorting networks).
 template <int MODE, bool BIGK, bool MASKS, bool G8 = false>
-__global__ void __launch_bounds__(G8 ? 512 : 256, 4) k_raster(const RasterParams P) {
+#ifndef UR_RASTER_WPS
+#define UR_RASTER_WPS 4  // waves per SIMD the register budget is set for
+#endif
+__global__ void __launch_bounds__(G8 ? 512 : 256, UR_RASTER_WPS) k_raster(const RasterParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(!G8 || MODE == 2, "eight-wave bins are the fused mode's");
   constexpr int BW = 16, BH = 16, WPB = G8 ? 8 : 4;
@@ -2410,16 +2416,19 @@ __global__ void __launch_bounds__(1024) k_project_faces_bwd_mesh(const float* __
 // them as [image][vertex][2]; the layered blend never reads depth, so there is no z term): the per-vertex half of
 // k_project_faces_bwd_mesh, same arithmetic, nothing to gather.  One workgroup per MESH: with M meshes tiled over
 // N = reps * M poses (image n = mesh n % M under pose n) it walks the mesh's poses in ascending order and adds their
-// vertex gradients up in registers (a fixed order: deterministic), so grad_verts is (M,V,3) with no copies of the
-// meshes anywhere; grad_R / grad_T stay per pose.
+// vertex gradients up (a fixed order: deterministic), so grad_verts is (M,V,3) with no copies of the meshes anywhere;
+// grad_R / grad_T stay per pose.  per_pose != 0 (no grad_verts wanted -- the pose step -- or no tiling): one workgroup
+// per POSE instead, nothing to add up across poses.
 __global__ void __launch_bounds__(1024) k_camera_bwd_mesh(const float* __restrict__ verts, const float* __restrict__ R,
                                                           const float* __restrict__ T, float sx, float sy, int V, int M,
-                                                          int reps, const float2* __restrict__ vsum,
+                                                          int reps, int per_pose, const float2* __restrict__ vsum,
                                                           float* __restrict__ gverts, float* __restrict__ gR,
                                                           float* __restrict__ gT) {
   __shared__ float part[16 * 12];
-  const int m = blockIdx.x, tid = threadIdx.x;
-  for (int k = 0; k < reps; ++k) {
+  const int tid = threadIdx.x;
+  const int m = per_pose ? (int)blockIdx.x % M : (int)blockIdx.x;
+  const int k_lo = per_pose ? (int)blockIdx.x / M : 0, k_hi = per_pose ? k_lo + 1 : reps;
+  for (int k = k_lo; k < k_hi; ++k) {
     const int n = k * M + m;
     const float* r = R + (int64_t)n * 9;
     const float* t = T + (int64_t)n * 3;
@@ -2440,7 +2449,7 @@ __global__ void __launch_bounds__(1024) k_camera_bwd_mesh(const float* __restric
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           const float c = gv[0] * r[i * 3 + 0] + gv[1] * r[i * 3 + 1] + gv[2] * r[i * 3 + 2];
-          go[i] = (k == 0) ? c : go[i] + c;
+          go[i] = (k == k_lo) ? c : go[i] + c;
         }
       }
 #pragma unroll
@@ -2450,7 +2459,7 @@ __global__ void __launch_bounds__(1024) k_camera_bwd_mesh(const float* __restric
       s[9] += gv[0]; s[10] += gv[1]; s[11] += gv[2];
     }
     if (!gR && !gT) continue;
-    if (k > 0) __syncthreads();  // the previous pose's partial sums have been read
+    if (k > k_lo) __syncthreads();  // the previous pose's partial sums have been read
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
       const float w = wave_sum(s[q]);
@@ -3342,9 +3351,10 @@ int ur_render_meshes_backward(const float* grad_image, const float* verts, const
                             faces_mesh_stride, M);
   if (rc || !geometry) return rc;
   if (vsum) {
-    if (M > 65535) return fail(UR_ERR_INVALID_ARG, "too many meshes per call");
-    hipLaunchKernelGGL(k_camera_bwd_mesh, dim3((unsigned)M), dim3(1024), 0, st, verts, R, T, sx, sy, V, M, N / M,
-                       reinterpret_cast<const float2*>(grad_face_verts), grad_verts, grad_R, grad_T);
+    if (N > 65535) return fail(UR_ERR_INVALID_ARG, "too many meshes per call");
+    const int per_pose = (M == N || !grad_verts) ? 1 : 0;
+    hipLaunchKernelGGL(k_camera_bwd_mesh, dim3((unsigned)(per_pose ? N : M)), dim3(1024), 0, st, verts, R, T, sx, sy, V, M,
+                       N / M, per_pose, reinterpret_cast<const float2*>(grad_face_verts), grad_verts, grad_R, grad_T);
     return check_launch("k_camera_bwd_mesh");
   }
   if (M != N) return fail(UR_ERR_UNSUPPORTED, "pose tiling needs per-vertex sums (V * 2 <= F * 9)");  // (check_tiling agrees)
