@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C4_B32_128x128_K50_ico3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-seconds", type=float, default=0.3, help="blocks of --steps timed steps are repeated until "
+                    "they add up to this long (0: one block; the counter passes of tools/prof_workload.sh use that)")
     ap.add_argument("--eager", action="store_true", help="time eager Python steps instead of replaying the step's "
                     "hipGraph (the eager rate is reported either way, as eager_images_per_s)")
     ap.add_argument("--grads", default=None, help="which inputs require grad, e.g. verts+texture+R+T (ablation only; "
@@ -218,7 +220,8 @@ def main():
     # reported loop is the replay of the step's hipGraph: the same kernels on the same buffers, one launch per step.
     # The eager loop is timed too, first (capturing afterwards leaves the leaves' AccumulateGrad nodes tied to the
     # capture stream, which would slow later eager steps down with stream syncs), and reported as a side field.
-    eager_blocks, eager_local = udist.timed_blocks(step, a.steps, a.warmup, world, cuda=True)
+    eager_blocks, eager_local = udist.timed_blocks(step, a.steps, a.warmup, world, cuda=True,
+                                                   min_seconds=a.min_seconds)
     eager_elapsed, eager_local_med = udist.median_block(eager_blocks, eager_local)
     launch, blocks, elapsed, local_elapsed, replay_elapsed = "eager", eager_blocks, eager_elapsed, eager_local_med, None
     if not a.eager:
@@ -230,7 +233,8 @@ def main():
                 img.backward(cot)
                 return img
             run = GraphedStep(body, grads_of=tuple(t for t in (verts, maps, R, T) if t.requires_grad))
-            blocks, replay_local = udist.timed_blocks(run, a.steps, a.warmup, world, cuda=True)
+            blocks, replay_local = udist.timed_blocks(run, a.steps, a.warmup, world, cuda=True,
+                                                       min_seconds=a.min_seconds)
             replay_elapsed, local_elapsed = udist.median_block(blocks, replay_local)
             elapsed = replay_elapsed
             launch = "hipGraph replay of one captured Renderer forward + backward"

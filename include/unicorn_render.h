@@ -206,7 +206,9 @@ int ur_blend_intermediates(const int32_t* pix_to_face, const float* dists, int N
  * the blend stops at the first layer that hides everything behind it (alpha == 1 with zero d(alpha)/d(dist)), which
  * changes neither the image nor any gradient.  No (N,H,W,K) fragment tensors are materialised: the forward leaves
  * only `layers`, ur_layers_elems() int32 words, opaque to the caller: per 16x16-pixel bin and per wavefront of the
- * bin (4 x 64 pixels, every second column / row) the layers that matter, one 32-byte row each (packed face index,
+ * bin (4 x 64 pixels, every second column / row -- or, in launches too small to fill the chip that way, N x bins <=
+ * 1024, 8 x 32 pixels, every second column / fourth row: a pure function of the sizes, the same in both calls of a
+ * step) the layers that matter, one 32-byte row each (packed face index,
  * pixel, float bits of the transmittance in front of the layer, its alpha and its colour), the layers of a pixel front
  * to back, pixel after pixel, followed by the per-pixel layer counts.  Only the rows of layers that exist are ever
  * touched.  The backward also needs ur_backward_scratch_bytes() of uninitialised device scratch.
