@@ -90,6 +90,24 @@ def one_case(rng, idx):
             e64 = rel(got.cpu().numpy(), g64[i])
             assert e64 <= 1e-4 + 30.0 * noise, desc + f" grad {name} {e:g} (vs float64 {e64:g}, float32 oracle's own noise {noise:g})"
             print("ill-conditioned:", desc, f"grad {name}: gpu vs oracle32 {e:g}, vs oracle64 {e64:g}, oracle32 vs oracle64 {noise:g}", flush=True)
+    # The same scene inside a batch big enough for the FOUR-wave build of the fused kernels (N x bins > 1024; a small
+    # launch like the one above runs eight waves of 32 pixels per bin): same pictures bit for bit, same gradients.
+    nbins = ((H + 15) // 16) * ((W + 15) // 16)
+    reps = 1024 // (N * nbins) + 1
+    if reps > 1 and reps * N <= 400:
+        g8 = [t.grad.clone() for t in (verts, maps, R, T)]
+        big = [t.detach().repeat(reps, *([1] * (t.dim() - 1))).requires_grad_(True) for t in (verts, maps, R, T)]
+        fb2 = sc["faces"].to(dev)[None].expand(reps * N, -1, -1)
+        ub2 = sc["verts_uvs"].to(dev)[None].expand(reps * N, -1, -1)
+        img2 = rend(Meshes(verts=big[0], faces=fb2, textures=TexturesUV(big[1], fb2, ub2)), big[2], big[3])
+        assert torch.equal(img2[:N], img) and torch.equal(img2[-N:], img), desc + " four-wave image != eight-wave image"
+        cot2 = torch.zeros_like(img2)
+        cot2[:N] = torch.from_numpy(cot).to(dev)
+        img2.backward(cot2)
+        for name, a, b in zip(("verts", "maps", "R", "T"), g8, big):
+            e = rel(b.grad[:N].cpu().numpy(), a.cpu().numpy())
+            assert e <= 5e-5, desc + f" four-wave vs eight-wave grad {name} {e:g}"
+            assert float(b.grad[N:].abs().max()) == 0.0, desc + " gradient leaked into a mesh with a zero cotangent"
     return desc
 
 
