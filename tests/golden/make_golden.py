@@ -68,7 +68,12 @@ def make_blend():
         img = blend(colors, frag, bp, clip_inside=clip_inside)
         (img * cot).sum().backward()
         gd = dists.grad if dists.grad is not None else torch.zeros_like(dists)
+        # the function's debug outputs (renderer.py:199-200): alphas + trailing 1, transmittance in front of each layer
+        with torch.no_grad():
+            _, dbg_alpha, dbg_occ, dbg_img = blend(colors.detach(), frag, bp, clip_inside=clip_inside, debug=True)
+        assert torch.equal(dbg_img, img.detach())
         np.savez(os.path.join(OUT, f"blend_{name}.npz"), pix_to_face=p2f.numpy(), dists=dists.detach().numpy(),
+                 debug_alpha=dbg_alpha.numpy(), debug_occ_alpha=dbg_occ.numpy(),
                  colors=colors.detach().numpy(), background=np.array(bgc, np.float32), sigma=np.float64(sigma),
                  clip_inside=np.bool_(clip_inside), image=img.detach().numpy(), cotangent=cot.numpy(),
                  grad_colors=colors.grad.numpy(), grad_dists=gd.numpy())

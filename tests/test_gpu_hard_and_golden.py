@@ -61,6 +61,10 @@ def test_blend_colors_against_reference_golden(golden_dir, name):
     col, p2f, ds = t(g["colors"]), t(g["pix_to_face"], np.int32), t(g["dists"])
     img = native.blend_colors(col, p2f, ds, None, kind, sigma, 1e-4, bg)
     np.testing.assert_allclose(img.cpu().numpy(), g["image"], atol=1e-5, rtol=0)
+    # the blend's intermediates (LayeredShader debug=True) against the reference function's own debug outputs
+    alpha, occ = native.blend_intermediates(p2f, ds, sigma, kind)
+    np.testing.assert_allclose(alpha.cpu().numpy(), g["debug_alpha"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(occ.cpu().numpy(), g["debug_occ_alpha"], atol=1e-6, rtol=0)
     gcol, gds, _ = native.blend_colors_backward(t(g["cotangent"]), col, p2f, ds, None, kind, sigma, 1e-4, bg)
     np.testing.assert_allclose(gcol.cpu().numpy(), g["grad_colors"], atol=1e-5, rtol=1e-4)
     scale = max(1.0, float(np.abs(g["grad_dists"]).max()))
