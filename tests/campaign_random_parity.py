@@ -108,6 +108,25 @@ def one_case(rng, idx):
             e = rel(b.grad[:N].cpu().numpy(), a.cpu().numpy())
             assert e <= 5e-5, desc + f" four-wave vs eight-wave grad {name} {e:g}"
             assert float(b.grad[N:].abs().max()) == 0.0, desc + " gradient leaked into a mesh with a zero cotangent"
+    # Pose tiling: the first mesh under all N poses, as an index (repeat -> n_meshes = 1) and as N
+    # physical copies: same pictures bit for bit, the one mesh's gradients summed over its poses.
+    if N > 1:
+        from unicorn_amd.structures import repeat
+        leaves = [t.detach()[:1].clone().requires_grad_(True) for t in (verts, maps)]
+        Rt, Tt = R.detach().clone().requires_grad_(True), T.detach().clone().requires_grad_(True)
+        one = Meshes(verts=leaves[0], faces=fb[:1], textures=TexturesUV(leaves[1], fb[:1], ub[:1]))
+        tiled = rend(repeat(one, N), Rt, Tt)
+        tiled.backward(torch.from_numpy(cot).to(dev))
+        got = [leaves[0].grad.clone(), leaves[1].grad.clone(), Rt.grad.clone(), Tt.grad.clone()]
+        for t in leaves + [Rt, Tt]:
+            t.grad = None
+        copies = Meshes(verts=leaves[0].repeat(N, 1, 1), faces=fb, textures=TexturesUV(leaves[1].repeat(N, 1, 1, 1), fb, ub))
+        img_c = rend(copies, Rt, Tt)
+        assert torch.equal(img_c, tiled), desc + " tiled image != copied image"
+        img_c.backward(torch.from_numpy(cot).to(dev))
+        for name, a, b in zip(("verts", "maps", "R", "T"), got, (leaves[0].grad, leaves[1].grad, Rt.grad, Tt.grad)):
+            e = rel(a.cpu().numpy(), b.cpu().numpy())
+            assert e <= 5e-5, desc + f" tiled vs copied grad {name} {e:g}"
     return desc
 
 
