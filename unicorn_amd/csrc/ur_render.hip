@@ -1886,13 +1886,13 @@ __device__ __forceinline__ void bary_path_bwd(const Face& f, const Eval& ev, flo
   o[0] += a0x; o[1] += a0y; o[2] += a1x; o[3] += a1y; o[4] += a2x; o[5] += a2y;
 }
 
-// claim-or-match a slot for `key` in an open-addressed LDS tag table of `slots` (a power of two) entries, starting at
-// its home slot h; returns the slot, or -1 when kProbes slots were all taken by other keys.  A global float atomic
-// costs far more than a few LDS round trips (4 % of the texel adds going to global memory were 7 us of a 53 us kernel).
+// claim-or-match a slot for `key` in an open-addressed LDS tag table of `slots` entries (a constant at every call site:
+// the modulo folds to a mask for a power of two, to a multiply-high otherwise), starting at its home slot h; returns the
+// slot, or -1 when kProbes slots were all taken by other keys.  A global float atomic costs far more than a few LDS round trips (4 % of the texel adds going to global memory were 7 us of a 53 us kernel).
 __device__ __forceinline__ int lds_claim(int* tags, int h, int key, int slots) {
 #pragma unroll
   for (int i = 0; i < kProbes; ++i) {
-    const int s = (h + i * kProbeStep) & (slots - 1);
+    const int s = (int)((unsigned)(h + i * kProbeStep) % (unsigned)slots);
     const int old = atomicCAS(&tags[s], -1, key);
     if (old == -1 || old == key) return s;
   }
@@ -2136,7 +2136,7 @@ __global__ void __launch_bounds__(W8 ? 512 : 256) k_render_bwd(const RasterParam
         o[4] += e01 ? 0.0f : gbx; o[5] += e01 ? 0.0f : gby;
       }
       if (P.gfv && (wgt != 0.0f || gd != 0.0f)) {
-        const int h = lds_claim(s_ftag, fid & (kFaceSlots - 1), fid, kFaceSlots);
+        const int h = lds_claim(s_ftag, (int)((unsigned)fid % (unsigned)kFaceSlots), fid, kFaceSlots);
         if (h >= 0) {
 #pragma unroll
           for (int i = 0; i < 6; ++i)
@@ -3197,10 +3197,10 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
 #define UR_BWD_W8 1  // (eight-wave bins are small launches: one wave per group gave the backward 39 -> 33 us at 32 x 64x64)
 #endif
     if (g8 && UR_BWD_W8) {
-      if (dense)
-        hipLaunchKernelGGL((k_render_bwd<512, 16, true, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, P);
-      else
-        hipLaunchKernelGGL((k_render_bwd<256, 32, true, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, P);
+      // two eight-wave workgroups per CU have 80 KB of LDS each: both tables at their larger size (45 KB).  It is the
+      // FACE table that needs it: a 16x16 bin of a 64x64 image sees more than 256 faces of a 1280-face mesh, and the
+      // ones that find no slot go to global atomics (32 x 64x64: 32.6 -> 26.8 us; 1024 texel slots add nothing)
+      hipLaunchKernelGGL((k_render_bwd<512, 32, true, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, P);
     } else if (dense && g8)
       hipLaunchKernelGGL((k_render_bwd<512, 16, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
     else if (dense)
@@ -3208,7 +3208,10 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
     else if (g8)
       hipLaunchKernelGGL((k_render_bwd<256, 32, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
     else
-      hipLaunchKernelGGL((k_render_bwd<256, 32, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
+#ifndef UR_BWD_FSLOTS
+#define UR_BWD_FSLOTS 256  // (A/B, profiles/r03_ab_bwd_tables.txt: 256 slots keep five workgroups on a CU; 384 (four) and
+#endif                     //  512 (three) are slower, 192 at six waves per SIMD spills)
+      hipLaunchKernelGGL((k_render_bwd<UR_BWD_FSLOTS, 32, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P);
   }
   return check_launch("k_render_bwd");
 }
