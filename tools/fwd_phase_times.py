@@ -44,6 +44,8 @@ run()
 torch.cuda.synchronize()
 L.ur_dev_set_timing(None)
 t = tim.view(nblk * 4, 16).cpu().double()
+if os.environ.get("UR_DEV_DUMP"):
+    torch.save(tim.view(nblk * 4, 16).cpu(), os.environ["UR_DEV_DUMP"])
 q = torch.tensor([.1, .5, .9, .99, 1.0], dtype=torch.double)
 
 

@@ -3196,6 +3196,10 @@ static int layered_backward(const float* grad_image, const int64_t* mesh_first_f
 #ifndef UR_BWD_W8
 #define UR_BWD_W8 1  // (eight-wave bins are small launches: one wave per group gave the backward 39 -> 33 us at 32 x 64x64)
 #endif
+    // (tried and dropped, profiles/r03_ab_bwd_split_fence.txt: two waves per 64-pixel group, the row list cut at a pixel
+    // boundary -- 512-thread workgroups, four waves per SIMD instead of five: 48 -> 54 us at 32 x 128x128, faster only
+    // for 16 x 256x256 / K=100 (372 -> 340 us) and slower again at 128 of those; a device-scope release fence per
+    // workgroup, which a "last workgroup runs the camera's backward" fusion would need: 48 -> 103 us)
     if (g8 && UR_BWD_W8) {
       // two eight-wave workgroups per CU have 80 KB of LDS each: both tables at their larger size (45 KB).  It is the
       // FACE table that needs it: a 16x16 bin of a 64x64 image sees more than 256 faces of a 1280-face mesh, and the
