@@ -196,3 +196,39 @@ def test_repeat_of_equal_sized_meshes_copies_nothing_until_asked():
     v2, f2 = synth.icosphere(2)
     h = repeat(Meshes([v, v2], [f, f2]), 2)
     assert not isinstance(h, TiledMeshes) and [x.shape[0] for x in h.verts_list()] == [42, 162, 42, 162]
+
+
+def test_join_meshes_as_batch_keeps_textures_and_shared_tables():
+    """pytorch3d's join_meshes_as_batch: batches in order, textures joined; tables that every input holds as an expanded
+    view of ONE tensor (unicorn.py:262-266,283) stay such a view, so the renderer's shared-table paths survive"""
+    v, f = synth.icosphere(1)
+    uvs = synth.spherical_uvs(v)
+    batches = []
+    for seed in range(3):
+        g = torch.Generator().manual_seed(seed)
+        verts = (v[None] + 0.01 * torch.randn(2, *v.shape, generator=g)).requires_grad_(True)
+        maps = torch.rand(2, 4, 4, 3, generator=g).requires_grad_(True)
+        fb, ub = f[None].expand(2, -1, -1), uvs[None].expand(2, -1, -1)
+        batches.append(Meshes(verts, fb, TexturesUV(maps, fb, ub)))
+    j = join_meshes_as_batch(batches)
+    assert len(j) == 6 and j.equisized
+    assert torch.equal(j.verts_padded()[2:4], batches[1].verts_padded())
+    assert torch.equal(j.textures.maps_padded()[4:], batches[2].textures.maps_padded())
+    assert j.faces_padded().stride(0) == 0 and j.faces_padded().data_ptr() == f.data_ptr()
+    assert j.textures._shared_tables() and j.textures.faces_uvs_padded().shape == (6, f.shape[0], 3)
+    (j.verts_padded().sum() + j.textures.maps_padded().sum()).backward()
+    assert all(torch.equal(b.verts_padded().grad, torch.ones_like(b.verts_padded())) for b in batches)
+    # per-mesh tables are concatenated; without textures on request; one batch is returned as it is
+    own = [Meshes(b.verts_padded().detach(), f[None].repeat(2, 1, 1), b.textures) for b in batches]
+    k = join_meshes_as_batch(own, include_textures=False)
+    assert k.textures is None and k.faces_padded().stride(0) != 0 and k.faces_padded().shape[0] == 6
+    assert join_meshes_as_batch([batches[0]]) is batches[0]
+    # vertex colours join too; mixed kinds do not
+    tv = [Meshes(b.verts_padded().detach(), b.faces_padded(), TexturesVertex(torch.rand(2, v.shape[0], 3))) for b in batches]
+    assert join_meshes_as_batch(tv).textures.verts_features_padded().shape == (6, v.shape[0], 3)
+    with pytest.raises(ValueError):
+        join_meshes_as_batch([batches[0], tv[0]])
+    # meshes of different sizes: joined through the lists
+    v2, f2 = synth.icosphere(2)
+    h = join_meshes_as_batch([Meshes(v[None], f[None]), Meshes(v2[None], f2[None])])
+    assert len(h) == 2 and not h.equisized

@@ -371,12 +371,57 @@ class Meshes:
         return sample_textures(self, fragments)
 
 
-def join_meshes_as_batch(meshes):
+def _same_expanded_table(tensors):
+    """the one table all of `tensors` are batch-expanded views of (stride 0 over the batch, same memory), or None"""
+    t0 = tensors[0]
+    if all(t.dim() == 3 and t.stride(0) == 0 and t.data_ptr() == t0.data_ptr() and t.shape[1:] == t0.shape[1:] and
+           t.stride()[1:] == t0.stride()[1:] for t in tensors):
+        return t0[:1]
+    return None
+
+
+def _cat_batches(tensors):
+    """torch.cat along the batch -- or, when every input is an expanded view of ONE table (the reference builds faces /
+    faces_uvs / verts_uvs with .expand, unicorn.py:262-266,283), that table expanded over the joined batch: the
+    renderer's shared-table fast paths survive the join"""
+    table = _same_expanded_table(tensors)
+    if table is not None:
+        return table.expand(sum(t.shape[0] for t in tensors), -1, -1)
+    return torch.cat(tensors, 0)
+
+
+def join_meshes_as_batch(meshes, include_textures=True):
+    """pytorch3d.structures.join_meshes_as_batch: one batch holding the meshes of all the given batches, in order,
+    textures joined too (all TexturesUV with maps of one size, or all TexturesVertex, or none).  Equal-sized inputs stay
+    padded tensors (one cat each); gradients flow back to every input.  What the 3D step needs to render its three
+    independent 32-mesh batches (unicorn.py:233, 411-413) in ONE renderer call."""
+    meshes = list(meshes)
+    if not meshes:
+        raise ValueError("no meshes to join")
+    if len(meshes) == 1:
+        return meshes[0]
+    tex = None
+    if include_textures:
+        texs = [m.textures for m in meshes]
+        if all(isinstance(t, TexturesUV) for t in texs):
+            if len({tuple(t.maps_padded().shape[1:]) for t in texs}) != 1:
+                raise ValueError("texture maps of different sizes cannot be joined")
+            tex = TexturesUV(torch.cat([t.maps_padded() for t in texs], 0),
+                             _cat_batches([t.faces_uvs_padded() for t in texs]),
+                             _cat_batches([t.verts_uvs_padded() for t in texs]))
+        elif all(isinstance(t, TexturesVertex) for t in texs):
+            tex = TexturesVertex(torch.cat([t.verts_features_padded() for t in texs], 0))
+        elif any(t is not None for t in texs):
+            raise ValueError("all meshes must have textures of one kind (or none) to be joined with them")
+    if all(m.equisized and len(m) > 0 for m in meshes):
+        vs, fs = [m.verts_padded() for m in meshes], [m.faces_padded() for m in meshes]
+        if len({v.shape[1] for v in vs}) == 1 and len({f.shape[1] for f in fs}) == 1:
+            return Meshes(torch.cat(vs, 0), _cat_batches(fs), tex)
     verts, faces = [], []
     for m in meshes:
         verts += m.verts_list()
         faces += m.faces_list()
-    return Meshes(verts, faces)
+    return Meshes(verts, faces, tex)
 
 
 class TiledTexturesUV(TexturesUV):
