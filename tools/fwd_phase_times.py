@@ -22,7 +22,8 @@ sigma = 1e-4
 blur = math.log(1.0 / 1e-4 - 1.0) * sigma
 fuv = sc["verts_uvs"][sc["faces"]].contiguous()
 nblk = B * ((H + 15) // 16) ** 2
-tim = torch.zeros(nblk * 64, dtype=torch.int64, device=dev)
+WPB = int(os.environ.get("UR_DEV_WPB", "4"))  # waves per bin: 8 when the launch is small enough for eight-wave bins
+tim = torch.zeros(nblk * WPB * 16, dtype=torch.int64, device=dev)
 L = native.lib()
 L.ur_dev_set_timing.argtypes = [ctypes.c_void_p]
 L.ur_dev_set_timing.restype = None
@@ -43,9 +44,9 @@ L.ur_dev_set_timing(ctypes.c_void_p(tim.data_ptr()))
 run()
 torch.cuda.synchronize()
 L.ur_dev_set_timing(None)
-t = tim.view(nblk * 4, 16).cpu().double()
+t = tim.view(nblk * WPB, 16).cpu().double()
 if os.environ.get("UR_DEV_DUMP"):
-    torch.save(tim.view(nblk * 4, 16).cpu(), os.environ["UR_DEV_DUMP"])
+    torch.save(tim.view(nblk * WPB, 16).cpu(), os.environ["UR_DEV_DUMP"])
 q = torch.tensor([.1, .5, .9, .99, 1.0], dtype=torch.double)
 
 
@@ -82,7 +83,7 @@ idx = torch.nonzero(live)[:, 0]
 for i in torch.argsort(us(w[:, 3] - t0), descending=True)[:8].tolist():
     print("  late wave: wg %5d wave %d start %7.1f end %7.1f ; scan %.1f pairs %.1f (%d batches) full-list %.1f (%d hits) "
           "compaction %.1f barrier %.1f sort %.1f shade %.1f ; items %d" % (
-              int(idx[i]) // 4, int(idx[i]) % 4, float(us(w[i, 0] - t0)), float(us(w[i, 3] - t0)), float(cu(w[i, 4])),
+              int(idx[i]) // WPB, int(idx[i]) % WPB, float(us(w[i, 0] - t0)), float(us(w[i, 3] - t0)), float(cu(w[i, 4])),
               float(cu(w[i, 5])), int(w[i, 11]), float(cu(w[i, 6])), int(w[i, 9]), float(cu(w[i, 7])), float(cu(w[i, 8])),
               float(us(w[i, 2] - w[i, 1])), float(us(w[i, 3] - w[i, 2])), int(w[i, 14])))
 # how full is the machine over time: waves alive in each tenth of the kernel
