@@ -232,3 +232,25 @@ def test_join_meshes_as_batch_keeps_textures_and_shared_tables():
     v2, f2 = synth.icosphere(2)
     h = join_meshes_as_batch([Meshes(v[None], f[None]), Meshes(v2[None], f2[None])])
     assert len(h) == 2 and not h.equisized
+
+
+def test_textures_sample_their_own_texels():
+    """pytorch3d's textures.sample_textures(fragments[, faces_packed]) -- what meshes.sample_textures(fragments) calls"""
+    from types import SimpleNamespace
+    v, f = synth.icosphere(1)
+    uvs = synth.spherical_uvs(v)
+    g = torch.Generator().manual_seed(3)
+    N, H, W, K = 2, 5, 4, 3
+    maps = torch.rand(N, 6, 6, 3, generator=g)
+    fb, ub = f[None].expand(N, -1, -1), uvs[None].expand(N, -1, -1)
+    m = Meshes(v[None].repeat(N, 1, 1), fb, TexturesUV(maps, fb, ub))
+    p2f = torch.randint(-1, f.shape[0], (N, H, W, K), generator=g)
+    p2f = torch.where(p2f >= 0, p2f + torch.arange(N).view(N, 1, 1, 1) * f.shape[0], p2f)
+    bary = torch.rand(N, H, W, K, 3, generator=g)
+    bary = bary / bary.sum(-1, keepdim=True)
+    frags = SimpleNamespace(pix_to_face=p2f, bary_coords=bary)
+    assert torch.equal(m.textures.sample_textures(frags), m.sample_textures(frags))
+    mv = Meshes(m.verts_padded(), fb, TexturesVertex(torch.rand(N, v.shape[0], 3, generator=g)))
+    assert torch.equal(mv.textures.sample_textures(frags, faces_packed=mv.faces_packed()), mv.sample_textures(frags))
+    with pytest.raises(ValueError):
+        mv.textures.sample_textures(frags)

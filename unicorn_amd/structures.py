@@ -89,6 +89,19 @@ class TexturesUV:
         r = lambda t: t.repeat_interleave(N, dim=0)
         return TexturesUV(r(self._maps), r(self._faces_uvs), r(self._verts_uvs))
 
+    def sample_textures(self, fragments, **kwargs):
+        """texels (N,H,W,K,C) of the fragments (pytorch3d TexturesUV.sample_textures; what
+        `meshes.sample_textures(fragments)` calls).  `fragments.pix_to_face` is packed over the batch this texture
+        object belongs to."""
+        from .shading import sample_textures
+
+        class _Holder:  # the mesh side of the call is only the batch length for UV textures
+            textures = self
+
+            def __len__(_):
+                return len(self)
+        return sample_textures(_Holder(), fragments)
+
     def __getitem__(self, index):
         index = [index] if isinstance(index, int) else index
         return TexturesUV(self._maps[index], self._faces_uvs[index], self._verts_uvs[index])
@@ -129,6 +142,15 @@ class TexturesVertex:
 
     def extend(self, N):
         return TexturesVertex(self._feat.repeat_interleave(N, dim=0))
+
+    def sample_textures(self, fragments, faces_packed=None):
+        """vertex features interpolated with the barycentrics (pytorch3d TexturesVertex.sample_textures): needs the
+        batch's packed faces"""
+        if faces_packed is None:
+            raise ValueError("TexturesVertex.sample_textures needs faces_packed")
+        from .shading import interpolate_face_attributes
+        return interpolate_face_attributes(fragments.pix_to_face, fragments.bary_coords,
+                                           self.verts_features_packed()[faces_packed])
 
     def __getitem__(self, index):
         index = [index] if isinstance(index, int) else index
