@@ -2,10 +2,12 @@
 //
 // Execution model (DESIGN.md 5 has the long version):
 //   * k_face_prep: one thread per face -> bounding box, per-face record (corners, denominators, RN reciprocals), and
-//     a per-bin load count; k_bin_order sorts the 16x16-pixel bins of all meshes heaviest first;
-//   * k_raster<MODE, BIGK>: one workgroup (4 waves) per bin, taken from that schedule.  Coarse step: the workgroup scans the
-//     mesh's face boxes (up to 8 coalesced float4 per lane), ballot + popcount prefix packs survivors into one bin
-//     list in LDS -- no atomics, deterministic; rounds of 2048 faces, the list cannot overflow.  Fine step: 64 bin
+//     a per-bin load count (one-call path, equal-sized meshes: k_project_prep_mesh does this together with the camera
+//     projection and leaves per-bin face masks); k_bin_order sorts the 16x16-pixel bins of all meshes heaviest first;
+//   * k_raster<MODE, BIGK, MASKS, G8>: one workgroup per bin, taken from that schedule: four waves of 64 pixels, or
+//     (G8, launches too small to fill the chip) eight waves of 32.  Coarse step: the workgroup scans the mesh's face
+//     boxes (up to 8 coalesced float4 per lane) or reads the bin's face mask, ballot + popcount prefix packs survivors
+//     into one bin list in LDS -- no atomics, deterministic; rounds of 2048 faces, the list cannot overflow.  Fine step: 64 bin
 //     faces at a time staged in LDS (double buffered).  MODE 0 (fragments): lane = pixel, faces walked one by one.
 //     MODE 2 (fused shading): (face, pixel) pairs dealt over the lanes, hits appended to per-pixel lists with LDS
 //     integer atomics.  MODE 1: tile lists exported;
