@@ -247,7 +247,9 @@ int ur_render_layered_backward(const float* grad_image, const int64_t* mesh_firs
  *   verts (N,V,3), faces / faces_mesh_stride as in ur_project_faces, mesh_first_face[n] = n*F, mesh_num_faces[n] = F ;
  *   face_verts (N*F,3,3): OUTPUT (the projected corners; the caller may want them, the backward does not) ;
  *   zero_grad_face_verts (N*F,3,3) / zero_grad_maps (N,Ht,Wt,3): optional buffers the forward clears on the way, to be
- *   handed to ur_render_meshes_backward with grads_are_zero = 1 (saves the backward a fill launch); NULL = skip.
+ *   handed to ur_render_meshes_backward with grads_are_zero = 1 (saves the backward a fill launch); NULL = skip.  Of
+ *   the first only the part the backward adds into is cleared: its first N*V*2 floats (per-vertex sums) when
+ *   V*2 <= F*9, else all of it.
  * Backward: grad_image (N,4,H,W) -> grad_maps (N,Ht,Wt,3), grad_verts (N,V,3), grad_R (N,3,3), grad_T (N,3); any may
  *   be NULL.  grad_face_verts (N*F,3,3 floats) is the intermediate accumulator (needed when any of grad_verts /
  *   grad_R / grad_T is wanted); its contents after the call are unspecified (this call keeps per-vertex sums in it,
