@@ -155,3 +155,63 @@ def test_gouraud_shading_matches_numpy():
         want = (bary[..., None] * lit[f][idx]).sum(-2) * mask
         got = lighting.gouraud_shading(meshes, frag, lights, lighting.Materials(), R, T).numpy()
         np.testing.assert_allclose(got, want, atol=1e-6)
+
+
+def test_interpolate_face_attributes_backward_equals_autograd_of_the_plain_formula():
+    """shading.interpolate_face_attributes carries its own backward (a scatter-add instead of autograd's sorting
+    index_put): values and both gradients must equal the plain gather-multiply-sum-mask formula's"""
+    import torch
+    from unicorn_amd.shading import interpolate_face_attributes
+    g = torch.Generator().manual_seed(0)
+    N, H, W, K, NF, D = 2, 5, 4, 3, 7, 4
+    p2f = torch.randint(-1, NF, (N, H, W, K), generator=g)
+    bary = torch.rand(N, H, W, K, 3, generator=g, dtype=torch.float64)
+    attrs = torch.randn(NF, 3, D, generator=g, dtype=torch.float64)
+    cot = torch.randn(N, H, W, K, D, generator=g, dtype=torch.float64)
+
+    def plain(b, a):
+        out = (b[..., None] * a[p2f.clamp(min=0)]).sum(-2)
+        return out.masked_fill((p2f < 0)[..., None], 0.0)
+    b1, a1 = bary.clone().requires_grad_(True), attrs.clone().requires_grad_(True)
+    b2, a2 = bary.clone().requires_grad_(True), attrs.clone().requires_grad_(True)
+    o1, o2 = interpolate_face_attributes(p2f, b1, a1), plain(b2, a2)
+    assert torch.equal(o1, o2)
+    o1.backward(cot)
+    o2.backward(cot)
+    valid = (p2f >= 0)[..., None].expand_as(bary)
+    assert torch.allclose(b1.grad[valid], b2.grad[valid], rtol=1e-12, atol=0)
+    assert float(b1.grad[~valid].abs().max()) == 0.0
+    assert torch.allclose(a1.grad, a2.grad, rtol=1e-12, atol=1e-14)
+    # whatever the empty slots' barycentrics hold does not leak (the plain formula's attribute gradient would be NaN)
+    b3 = bary.clone()
+    b3[p2f < 0] = float("nan")
+    b3, a3 = b3.requires_grad_(True), attrs.clone().requires_grad_(True)
+    o3 = interpolate_face_attributes(p2f, b3, a3)
+    o3.backward(cot)
+    assert torch.equal(o3, o1) and torch.equal(a3.grad, a1.grad) and torch.equal(b3.grad, b1.grad)
+
+
+def test_gather_rows_backward():
+    import torch
+    from unicorn_amd.shading import gather_rows
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(6, 3, generator=g, dtype=torch.float64)
+    idx = torch.randint(0, 6, (2, 4, 5), generator=g)
+    cot = torch.randn(2, 4, 5, 3, generator=g, dtype=torch.float64)
+    t1, t2 = table.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    o1, o2 = gather_rows(t1, idx), t2[idx]
+    assert torch.equal(o1, o2)
+    o1.backward(cot)
+    o2.backward(cot)
+    assert torch.allclose(t1.grad, t2.grad, rtol=1e-12, atol=1e-14)
+
+
+def test_gather_rows_ignores_empty_slots():
+    import torch
+    from unicorn_amd.shading import gather_rows
+    table = torch.arange(12, dtype=torch.float64).view(4, 3).requires_grad_(True)
+    idx = torch.tensor([[2, -1, 0], [-1, -1, 3]])
+    out = gather_rows(table, idx)
+    assert torch.equal(out[0, 0], table[2].detach()) and torch.equal(out[1, 2], table[3].detach())
+    out.backward(torch.ones_like(out))
+    assert torch.equal(table.grad, torch.tensor([[1.0] * 3, [0.0] * 3, [1.0] * 3, [1.0] * 3], dtype=torch.float64))

@@ -254,3 +254,35 @@ def test_textures_sample_their_own_texels():
     assert torch.equal(mv.textures.sample_textures(frags, faces_packed=mv.faces_packed()), mv.sample_textures(frags))
     with pytest.raises(ValueError):
         mv.textures.sample_textures(frags)
+
+
+def test_sample_textures_equals_grid_sample_with_empty_slots_at_the_origin():
+    """pytorch3d's TexturesUV.sample_textures: uv interpolated with the barycentrics (0 at empty slots), then
+    grid_sample(flip(maps), 2uv-1, bilinear, align_corners, border).  The implementation samples empty slots
+    elsewhere and patches their value in (no contended atomics in the backward): texels and the maps' gradient must
+    be those of the plain formula."""
+    from types import SimpleNamespace
+    from torch.nn import functional as F
+    v, f = synth.icosphere(1)
+    uvs = synth.spherical_uvs(v)
+    g = torch.Generator().manual_seed(4)
+    N, H, W, K = 2, 6, 5, 4
+    fb, ub = f[None].expand(N, -1, -1), uvs[None].expand(N, -1, -1)
+    p2f = torch.randint(-60, f.shape[0], (N, H, W, K), generator=g).clamp(min=-1)
+    p2f = torch.where(p2f >= 0, p2f + torch.arange(N).view(N, 1, 1, 1) * f.shape[0], p2f)
+    bary = torch.rand(N, H, W, K, 3, generator=g)
+    bary = bary / bary.sum(-1, keepdim=True)
+    cot = torch.randn(N, H, W, K, 3, generator=g)
+    frags = SimpleNamespace(pix_to_face=p2f, bary_coords=bary)
+    m1 = torch.rand(N, 7, 9, 3, generator=g).requires_grad_(True)
+    m2 = m1.detach().clone().requires_grad_(True)
+    got = Meshes(v[None].repeat(N, 1, 1), fb, TexturesUV(m1, fb, ub)).sample_textures(frags)
+    fuv = uvs[f]                                                   # (F,3,2)
+    uv = (bary[..., None] * fuv.repeat(N, 1, 1)[p2f.clamp(min=0)]).sum(-2).masked_fill((p2f < 0)[..., None], 0.0)
+    grid = (uv * 2 - 1).permute(0, 3, 1, 2, 4).reshape(N, K * H, W, 2)
+    want = F.grid_sample(torch.flip(m2.permute(0, 3, 1, 2), [2]), grid, mode="bilinear", align_corners=True,
+                         padding_mode="border").view(N, 3, K, H, W).permute(0, 3, 4, 2, 1)
+    assert torch.allclose(got, want, rtol=0, atol=1e-6) and int((p2f < 0).sum()) > 50
+    got.backward(cot)
+    want.backward(cot)
+    assert torch.allclose(m1.grad, m2.grad, rtol=1e-5, atol=1e-5)

@@ -109,9 +109,9 @@ def flat_shading(meshes, fragments, lights, materials, texels, R, T):
     centers, fnorm = fv.mean(1), meshes.faces_normals_packed()
     p2f = fragments.pix_to_face
     mask = (p2f < 0)[..., None]
-    idx = p2f.clamp(min=0)
-    coords = centers[idx].masked_fill(mask, 0.0)
-    normals = fnorm[idx].masked_fill(mask, 0.0)
+    from .shading import gather_rows
+    coords = gather_rows(centers, p2f.long()).masked_fill(mask, 0.0)
+    normals = gather_rows(fnorm, p2f.long()).masked_fill(mask, 0.0)
     amb, dif, spe = light_terms(lights, materials, coords, normals, camera_center(R, T))
     return (amb + dif) * texels + spe
 
