@@ -2218,10 +2218,11 @@ __global__ void __launch_bounds__(256) k_shade_fwd(const ShadeParams P) {
     const int64_t e = pix * P.K + k;
     const int fid = P.p2f[e];
     const bool valid = fid >= 0;
+    if (!valid) continue;  // an empty slot: alpha 0 -- it adds +0 to the colour and leaves the transmittance as it is
     const float a = layer_alpha(P.dists[e], valid, P.sigma, P.mode);
     float u = 0.0f, v = 0.0f;
     const float* fu;
-    if (valid) frag_uv(P, n, fid, e, u, v, fu);
+    frag_uv(P, n, fid, e, u, v, fu);
     const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
     float cr, cg, cb;
     sample_rgb(map, bl, P.Ht, P.Wt, cr, cg, cb);
@@ -2263,12 +2264,19 @@ __global__ void __launch_bounds__(64) k_shade_bwd(const ShadeParams P) {
     const int64_t e = pix * P.K + k;
     const int fid = P.p2f[e];
     const bool valid = fid >= 0;
+    if (!valid) {
+      // an empty slot (most of a K-deep fragment tensor): alpha 0, no gradient anywhere, and the sweep's running
+      // values pass it unchanged -- none of the texture reads and arithmetic below
+      P.gdists[e] = 0.0f;
+      P.gbary[e * 3 + 0] = 0.0f; P.gbary[e * 3 + 1] = 0.0f; P.gbary[e * 3 + 2] = 0.0f;
+      continue;
+    }
     const float d = P.dists[e];
     const float a = layer_alpha(d, valid, P.sigma, P.mode);
     const float ok = s_occ[k * 64 + t];
     float u = 0.0f, v = 0.0f;
     const float* fu = nullptr;
-    if (valid) frag_uv(P, n, fid, e, u, v, fu);
+    frag_uv(P, n, fid, e, u, v, fu);
     const Bilin bl = bilin_setup(u, v, P.Ht, P.Wt);
     int onw, one, osw, ose;
     bilin_offsets(bl, P.Ht, P.Wt, onw, one, osw, ose);
