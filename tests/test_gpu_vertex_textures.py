@@ -174,3 +174,37 @@ def test_transform_points_screen_is_the_rasterizers_pixel_grid(H, W):
     for n in range(N):
         rows, cols = np.nonzero(p2f[n] >= 0)
         assert list(zip(cols, rows)) == [(pix[n, 0], pix[n, 1])], (n, list(zip(cols, rows)), pix[n])
+
+
+def test_batch_of_unequal_meshes_with_vertex_colours():
+    """meshes of different sizes in one batch (lists; pytorch3d's TexturesVertex takes a list of (V_n, C) tensors): each
+    image, and each mesh's gradients, must be what rendering that mesh alone gives (images are independent units)"""
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesVertex
+    dev = torch.device("cuda:0")
+    H = W = 48
+    sc = synth.make_scene(3, level=3, seed=21)
+    v2, f2 = synth.icosphere(2)
+    verts = [sc["verts"][0].to(dev), (v2 * 0.45).to(dev), sc["verts"][2].to(dev)]
+    faces = [sc["faces"].to(dev), f2.to(dev), sc["faces"].to(dev)]
+    rs = np.random.RandomState(5)
+    cols = [torch.from_numpy(rs.rand(v.shape[0], 3).astype(np.float32)).to(dev) for v in verts]
+    R, T = sc["R"].to(dev), sc["T"].to(dev)
+    cot = torch.from_numpy(rs.randn(3, 4, H, W).astype(np.float32)).to(dev)
+    rend = Renderer((H, W), cameras={"name": "fov", "fov": 30}, faces_per_pixel=10, sigma=1e-4).to(dev)
+
+    def leaves():
+        return [v.clone().requires_grad_(True) for v in verts], [c.clone().requires_grad_(True) for c in cols]
+    vb, cb = leaves()
+    out = rend(Meshes(vb, faces, TexturesVertex(cb)), R, T)
+    assert out.shape == (3, 4, H, W)
+    out.backward(cot)
+    for i in range(3):
+        vi, ci = leaves()
+        alone = rend(Meshes([vi[i]], [faces[i]], TexturesVertex([ci[i]])), R[i:i + 1], T[i:i + 1])
+        # (a list batch is projected by torch ops in the kernel's operation order, a single mesh by k_project_faces)
+        assert torch.equal(alone[0], out[i].detach()), f"image {i}: {float((alone[0] - out[i].detach()).abs().max()):g}"
+        alone.backward(cot[i:i + 1])
+        assert rel_err(vb[i].grad.cpu().numpy(), vi[i].grad.cpu().numpy()) <= 1e-4
+        assert rel_err(cb[i].grad.cpu().numpy(), ci[i].grad.cpu().numpy()) <= 1e-4
+        assert 0.02 < float(out[i, 3].detach().mean()) < 0.9

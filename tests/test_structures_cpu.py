@@ -286,3 +286,15 @@ def test_sample_textures_equals_grid_sample_with_empty_slots_at_the_origin():
     got.backward(cot)
     want.backward(cot)
     assert torch.allclose(m1.grad, m2.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_vertex_textures_of_unequal_meshes():
+    """pytorch3d's TexturesVertex takes a list of (V_n, C) tensors of different lengths: padded / packed / list views"""
+    a, b = torch.rand(5, 3), torch.rand(3, 3)
+    t = TexturesVertex([a, b])
+    assert len(t) == 2 and t.verts_features_padded().shape == (2, 5, 3) and t._num_verts_per_mesh == [5, 3]
+    assert torch.equal(t.verts_features_packed(), torch.cat([a, b])) and torch.equal(t.verts_features_list()[1], b)
+    assert torch.equal(t.verts_features_padded()[1, 3:], torch.zeros(2, 3))
+    assert torch.equal(t[1].verts_features_packed(), b) and torch.equal(t[[1, 0]].verts_features_list()[1], a)
+    assert torch.equal(t.extend(2).verts_features_packed(), torch.cat([a, a, b, b]))
+    assert torch.equal(t.clone().detach().verts_features_packed(), t.verts_features_packed())

@@ -74,6 +74,41 @@ for name, kw in (("LayeredShader shading_type=phong, directional light", dict(sh
                  ("SoftPhongShaderPlus (layered_shader=False), point light", dict(layered_shader=False, lights={"name": "point"}))):
     r = Renderer(64, cameras=cam, faces_per_pixel=25, sigma=1e-4, **kw).to(dev)
     out[name + ", 32x64x64 K=25, fwd+bwd (eager)"] = timed(fwd_bwd(r, leaves, fb, ub, cot))
+# the other shading types, vertex colours, and a batch of unequal meshes (lists: the projected-faces route)
+from unicorn_amd.structures import TexturesVertex  # noqa: E402
+for name, kw in (("LayeredShader shading_type=flat, point light", dict(shading_type="flat", lights={"name": "point"})),):
+    r = Renderer(64, cameras=cam, faces_per_pixel=25, sigma=1e-4, **kw).to(dev)
+    out[name + ", 32x64x64 K=25, fwd+bwd (eager)"] = timed(fwd_bwd(r, leaves, fb, ub, cot))
+vcol = torch.rand(B, leaves[0].shape[1], 3, device=dev, requires_grad=True)
+for name, kw in (("TexturesVertex, raw shading", dict()),
+                 ("TexturesVertex, shading_type=gouraud, directional light", dict(shading_type="gouraud", lights={"name": "directional"}))):
+    r = Renderer(64, cameras=cam, faces_per_pixel=25, sigma=1e-4, **kw).to(dev)
+
+    def vstep(r=r):
+        for t in (leaves[0], leaves[2], leaves[3], vcol):
+            t.grad = None
+        r(Meshes(verts=leaves[0], faces=fb, textures=TexturesVertex(vcol)), leaves[2], leaves[3]).backward(cot)
+    out[name + ", 32x64x64 K=25, fwd+bwd (eager)"] = timed(vstep)
+r = Renderer(64, cameras=cam, faces_per_pixel=25, sigma=1e-4).to(dev)
+v2, f2 = synth.icosphere(2)
+v2 = (v2 * 0.5).to(dev)
+f2 = f2.to(dev)
+uv2 = synth.spherical_uvs(v2.cpu()).to(dev)
+
+
+def hetero():
+    for t in leaves:
+        t.grad = None
+    vl = [leaves[0][i] if i % 2 == 0 else v2 for i in range(B)]
+    fl = [fb[i] if i % 2 == 0 else f2 for i in range(B)]
+    # (TexturesUV wants one face count: per-mesh tables padded to the larger mesh)
+    r(Meshes(vl, fl, TexturesVertex([torch.ones_like(x) * 0.5 for x in vl])), leaves[2], leaves[3]).backward(cot)
+
+
+try:
+    out["batch of unequal meshes (ico3 / ico2 alternating, vertex colours), 32x64x64 K=25, fwd+bwd (eager)"] = timed(hetero)
+except Exception as e:  # a path this build does not serve is reported, not hidden
+    print("unequal meshes:", type(e).__name__, e, file=sys.stderr, flush=True)
 # visualisation path and vertex visibility (hard raster at 512x512, K=1, 2x2 average), no gradients
 leaves, fb, ub = scene(B, grad=False)
 rend = Renderer(64, cameras=cam, faces_per_pixel=25, sigma=1e-4).to(dev)

@@ -161,13 +161,18 @@ class MeshRasterizer(nn.Module):
             face_verts = ops.project_faces(verts.float(), faces.contiguous(), R.float(), T.float(), sx, sy)
             first, nf = self._mesh_index(N, Fn, verts.device)
             return face_verts, first, nf
-        # heterogeneous batch: plain tensor ops on the packed representation (not the reference's case)
+        # heterogeneous batch: plain tensor ops on the packed representation (not the reference's case), in the
+        # kernels' operation order -- ((p0 r0c + p1 r1c) + p2 r2c) + tc, then (s x) / z -- one rounding per torch op, so
+        # a mesh renders bit for bit as it does alone through k_project_faces
+        from .shading import gather_rows
         idx = meshes.verts_packed_to_mesh_idx()
-        v = meshes.verts_packed()
-        view = torch.bmm(v[:, None], R[idx])[:, 0] + T[idx]
-        z = view[:, 2]
-        ndc = torch.stack([sx * view[:, 0] / z, sy * view[:, 1] / z, z], -1)
-        return ndc[meshes.faces_packed()], meshes.mesh_to_faces_packed_first_idx(), meshes.num_faces_per_mesh()
+        p = meshes.verts_packed().float()
+        Ri, Ti = R.float()[idx], T.float()[idx]
+        vx, vy, vz = (((p[:, 0] * Ri[:, 0, c] + p[:, 1] * Ri[:, 1, c]) + p[:, 2] * Ri[:, 2, c]) + Ti[:, c]
+                      for c in range(3))
+        ndc = torch.stack([(sx * vx) / vz, (sy * vy) / vz, vz], -1)
+        return (gather_rows(ndc, meshes.faces_packed()), meshes.mesh_to_faces_packed_first_idx(),
+                meshes.num_faces_per_mesh())
 
     def forward(self, meshes, R=None, T=None, **kwargs):
         rs = kwargs.get("raster_settings", self.raster_settings)

@@ -111,12 +111,20 @@ class TexturesVertex:
     """Per-vertex features (N,V,C), interpolated with the barycentrics."""
 
     def __init__(self, verts_features):
+        self._list = None  # only for a batch of meshes with different vertex counts (pytorch3d takes such a list)
         if not torch.is_tensor(verts_features):
-            verts_features = torch.stack(list(verts_features))
+            feats = list(verts_features)
+            if len({f.shape[0] for f in feats}) > 1:
+                self._list = feats
+                V = max(f.shape[0] for f in feats)
+                verts_features = torch.stack([torch.nn.functional.pad(f, (0, 0, 0, V - f.shape[0])) for f in feats])
+            else:
+                verts_features = torch.stack(feats)
         if verts_features.dim() != 3:
             raise ValueError("verts_features must be (N,V,C)")
         self._feat = verts_features
-        self._num_verts_per_mesh = [verts_features.shape[1]] * len(verts_features)
+        self._num_verts_per_mesh = ([f.shape[0] for f in self._list] if self._list is not None
+                                    else [verts_features.shape[1]] * len(verts_features))
         self.device = verts_features.device
 
     def __len__(self):
@@ -126,21 +134,28 @@ class TexturesVertex:
         return self._feat
 
     def verts_features_packed(self):
+        if self._list is not None:
+            return torch.cat(self._list, 0)
         return self._feat.reshape(-1, self._feat.shape[-1])
 
     def verts_features_list(self):
-        return list(self._feat.unbind(0))
+        return list(self._list) if self._list is not None else list(self._feat.unbind(0))
+
+    def _map(self, fn):
+        return TexturesVertex([fn(f) for f in self._list]) if self._list is not None else TexturesVertex(fn(self._feat))
 
     def detach(self):
-        return TexturesVertex(self._feat.detach())
+        return self._map(lambda t: t.detach())
 
     def clone(self):
-        return TexturesVertex(self._feat.clone())
+        return self._map(lambda t: t.clone())
 
     def to(self, device):
-        return TexturesVertex(self._feat.to(device))
+        return self._map(lambda t: t.to(device))
 
     def extend(self, N):
+        if self._list is not None:
+            return TexturesVertex([f for f in self._list for _ in range(N)])
         return TexturesVertex(self._feat.repeat_interleave(N, dim=0))
 
     def sample_textures(self, fragments, faces_packed=None):
@@ -154,6 +169,14 @@ class TexturesVertex:
 
     def __getitem__(self, index):
         index = [index] if isinstance(index, int) else index
+        if self._list is not None:
+            if isinstance(index, slice):
+                picked = self._list[index]
+            else:
+                index = torch.as_tensor(index)
+                index = index.nonzero()[:, 0] if index.dtype == torch.bool else index
+                picked = [self._list[int(i)] for i in index.reshape(-1)]
+            return TexturesVertex(picked)
         return TexturesVertex(self._feat[index])
 
 
