@@ -215,3 +215,22 @@ def test_gather_rows_ignores_empty_slots():
     assert torch.equal(out[0, 0], table[2].detach()) and torch.equal(out[1, 2], table[3].detach())
     out.backward(torch.ones_like(out))
     assert torch.equal(table.grad, torch.tensor([[1.0] * 3, [0.0] * 3, [1.0] * 3, [1.0] * 3], dtype=torch.float64))
+
+
+def test_per_view_light_directions_as_the_eye_light_turntable_sets_them():
+    """renderer.py:249-250 assigns lights.direction = [[0, 0, -1]] @ R_view^T, a (B, 1, 3) tensor; the reference's light
+    functions view any such property as (-1, ..., 3) (pytorch3d_monkey.py:99-109)"""
+    import torch
+    from types import SimpleNamespace
+    from unicorn_amd.lighting import Materials, light_terms
+    g = torch.Generator().manual_seed(2)
+    N = 4
+    pts, nrm = torch.randn(N, 5, 6, 2, 3, generator=g), torch.randn(N, 5, 6, 2, 3, generator=g)
+    d = torch.randn(N, 3, generator=g)
+    cam = torch.randn(N, 3, generator=g)
+    mk = lambda direction: SimpleNamespace(ambient_color=((0.7, 0.7, 0.7),), diffuse_color=((0.3, 0.3, 0.3),),
+                                           specular_color=((0.1, 0.1, 0.1),), direction=direction)
+    a = light_terms(mk(d), Materials(), pts, nrm, cam)
+    b = light_terms(mk(d[:, None, :]), Materials(), pts, nrm, cam)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[1][0], a[1][1] * 0 + a[1][0].mean())  # (the term does vary over the batch)

@@ -13,8 +13,10 @@ from torch.nn import functional as F
 
 
 def _t(x, device):
+    """a light / material property as (1|N, 3): the reference views whatever it is given as (-1, ..., 3)
+    (pytorch3d_monkey.py:99-109), e.g. the (B, 1, 3) per-view directions of the eye-light GIFs (renderer.py:249-250)"""
     t = torch.as_tensor(x, dtype=torch.float32, device=device)
-    return t if t.dim() == 2 else t.view(1, -1)
+    return t if t.dim() == 2 else t.reshape(-1, 3)
 
 
 class Materials:

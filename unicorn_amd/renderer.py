@@ -13,7 +13,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import lighting, native, ops
-from .cameras import FoVPerspectiveCameras, PerspectiveCameras
+from .cameras import FoVPerspectiveCameras, PerspectiveCameras, look_at_view_transform
 from .structures import Meshes, TexturesUV, TexturesVertex  # noqa: F401  (re-exported for callers)
 
 LAYERED_SHADER = True
@@ -468,3 +468,43 @@ class Renderer(nn.Module):
         vis = torch.zeros(n_verts, dtype=torch.bool, device=p2f.device)
         vis[packed_faces[face_visible[1:]].flatten()] = True
         return vis.view(len(meshes), -1)
+
+
+@torch.no_grad()
+def render_rotated_views(mesh, img_size=256, n_views=50, elev=30, dist=2.5, R=None, T=None, bkg=None, renderer=None,
+                         rend_kwargs=None, eye_light=False, device=None):
+    """(n_views, 3, img_size, img_size) turntable of ONE mesh through the visualisation path, composited over `bkg` if
+    given -- the reference's helper of the same name (renderer.py:219-257), which `save_mesh_as_gif` wraps.  With
+    `eye_light` an ambient-lit renderer is rebuilt with a headlight (directional, along the view axis, phong, K=1)
+    that follows the camera; a given (R, T) is applied on top of the orbit (then elev / dist are taken as 0)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    renderer = renderer if renderer is not None else Renderer(img_size, **(rend_kwargs or {}))
+    if eye_light:
+        if R is not None:
+            raise NotImplementedError
+        if isinstance(renderer.lights, AmbientLights) and not hasattr(renderer.lights, "diffuse_color"):
+            kw = renderer.init_kwargs
+            kw.update(lights={"name": "directional", "direction": [[0, 0, -1]], "ambient_color": [[0.7, 0.7, 0.7]],
+                              "diffuse_color": [[0.3, 0.3, 0.3]], "specular_color": [[0.0, 0.0, 0.0]]},
+                      shading_type="phong", faces_per_pixel=1)
+            renderer = Renderer(img_size, **kw)
+    elev = 0 if R is not None else elev
+    dist = 0 if T is not None else dist
+    R = torch.eye(3, device=device) if R is None else R.to(device)
+    T = torch.zeros(3, device=device) if T is None else T.to(device)
+    if bkg is not None and bkg.shape[-1] != img_size:
+        bkg = torch.nn.functional.interpolate(bkg[None], size=(img_size, img_size), mode="bilinear",
+                                              align_corners=False)[0]
+    mesh, renderer = mesh.to(device), renderer.to(device)
+    azim = torch.linspace(-180, 180, n_views)
+    views, per_call = [], 10  # (the reference's batch of views per call)
+    for k in range(0, n_views, per_call):
+        R_view = look_at_view_transform(dist=1, elev=elev, azim=azim[k:k + per_call], device=device)[0]
+        n = R_view.shape[0]
+        T_view = torch.tensor([[0.0, 0.0, float(dist)]], device=device).expand(n, -1)
+        if eye_light:  # the light points where the camera looks: (n, 1, 3)
+            renderer.update_lights(direction=torch.tensor([[0.0, 0.0, -1.0]], device=device) @ R_view.transpose(1, 2))
+        views.append(renderer(mesh.extend(n), R_view @ R, T_view + T, viz_purpose=True).clamp(0, 1).cpu())
+    rec, alpha = torch.cat(views, 0).split([3, 1], dim=1)
+    return rec if bkg is None else rec * alpha + (1 - alpha) * bkg.cpu()
+
