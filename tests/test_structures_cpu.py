@@ -298,3 +298,21 @@ def test_vertex_textures_of_unequal_meshes():
     assert torch.equal(t[1].verts_features_packed(), b) and torch.equal(t[[1, 0]].verts_features_list()[1], a)
     assert torch.equal(t.extend(2).verts_features_packed(), torch.cat([a, a, b, b]))
     assert torch.equal(t.clone().detach().verts_features_packed(), t.verts_features_packed())
+
+
+def test_faces_verts_textures_packed_reads_the_texture_at_the_corners():
+    """pytorch3d TexturesUV.faces_verts_textures_packed (utils/mesh.py:162-165 builds vertex colours from it): uv (u, v)
+    reads map row (1 - v) * (Ht - 1), column u * (Wt - 1), bilinearly"""
+    Ht, Wt = 5, 7
+    maps = torch.rand(2, Ht, Wt, 3, generator=torch.Generator().manual_seed(6))
+    # corners placed on texel centres, plus one half-way between two texels
+    uvs = torch.tensor([[0.0, 0.0], [1.0, 1.0], [2 / 6, 3 / 4], [0.5 / 6, 0.0]])
+    faces = torch.tensor([[0, 1, 2], [2, 3, 0]])
+    t = TexturesUV(maps, faces[None].expand(2, -1, -1), uvs[None].expand(2, -1, -1))
+    out = t.faces_verts_textures_packed()
+    assert out.shape == (4, 3, 3)
+    m = maps[1]
+    want = {0: m[Ht - 1, 0], 1: m[0, Wt - 1], 2: m[1, 2], 3: 0.5 * (m[Ht - 1, 0] + m[Ht - 1, 1])}
+    for face in range(2):
+        for corner in range(3):
+            assert torch.allclose(out[2 + face, corner], want[int(faces[face, corner])], atol=1e-6)

@@ -89,6 +89,17 @@ class TexturesUV:
         r = lambda t: t.repeat_interleave(N, dim=0)
         return TexturesUV(r(self._maps), r(self._faces_uvs), r(self._verts_uvs))
 
+    def faces_verts_textures_packed(self):
+        """(sum F, 3, C): the texture's colour at every face corner's uv (pytorch3d's method of the same name; the
+        reference turns UV textures into vertex colours with it, utils/mesh.py:162-165).  Same sampling as
+        sample_textures: bilinear, align_corners=True, border padding, v axis flipped."""
+        N, F = self._faces_uvs.shape[:2]
+        uv = torch.gather(self._verts_uvs, 1, self._faces_uvs.reshape(N, F * 3, 1).expand(-1, -1, 2))  # (N, F*3, 2)
+        maps = torch.flip(self._maps.permute(0, 3, 1, 2), [2])
+        tex = torch.nn.functional.grid_sample(maps, (uv * 2.0 - 1.0)[:, :, None, :], mode="bilinear", align_corners=True,
+                                              padding_mode="border")                                  # (N, C, F*3, 1)
+        return tex[..., 0].permute(0, 2, 1).reshape(N * F, 3, -1)
+
     def sample_textures(self, fragments, **kwargs):
         """texels (N,H,W,K,C) of the fragments (pytorch3d TexturesUV.sample_textures; what
         `meshes.sample_textures(fragments)` calls).  `fragments.pix_to_face` is packed over the batch this texture
