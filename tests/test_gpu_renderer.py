@@ -456,3 +456,40 @@ def test_one_call_render_step_equals_the_composed_entry_points():
     verts.grad = None
     img.backward(cot)
     assert rel_err(verts.grad.cpu().numpy(), first_pass.cpu().numpy()) <= 1e-5
+
+
+def test_meshes_built_the_reference_way_render_like_plain_tensors():
+    """unicorn.py:259-266 builds the batch as template.extend(B) -> offset_verts_(packed displacements) -> textures =
+    TexturesUV(maps, faces[None].expand, uvs.expand) -> scale_verts_((B, 3) scales), and renders it (unicorn.py:233):
+    same picture and same gradients as a batch built from the final vertex tensor directly"""
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesUV
+    dev = torch.device("cuda:0")
+    B, H = 3, 48
+    sc = synth.make_scene(B, level=2, tex_size=16, seed=9, device=dev)
+    tmpl_v, faces = sc["verts"][0] * 0 + synth.icosphere(2)[0].to(dev) * 0.5, sc["faces"]
+    uvs = sc["verts_uvs"][None]
+    g = torch.Generator(device=dev).manual_seed(1)
+    disp0 = 0.03 * torch.randn(B * tmpl_v.shape[0], 3, device=dev, generator=g)
+    scales0 = 1.0 + 0.2 * torch.rand(B, 3, device=dev, generator=g)
+    maps0 = sc["maps"].permute(0, 3, 1, 2).contiguous()                    # BCHW, as the texture generator emits them
+    cot = torch.randn(B, 4, H, H, device=dev, generator=g)
+    rend = Renderer(H, cameras={"name": "fov", "fov": 30}, faces_per_pixel=10, sigma=1e-4).to(dev)
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in (disp0, scales0, maps0)]
+    disp, scales, maps = leaves()
+    meshes = Meshes(tmpl_v[None], faces[None]).extend(B)
+    meshes.offset_verts_(disp)
+    meshes.textures = TexturesUV(maps.permute(0, 2, 3, 1), faces[None].expand(B, -1, -1), uvs.expand(B, -1, -1))
+    meshes.scale_verts_(scales)
+    img = rend(meshes, sc["R"], sc["T"])
+    img.backward(cot)
+    d2, s2, m2 = leaves()
+    verts = (tmpl_v[None] + d2.view(B, -1, 3)) * s2[:, None]
+    fb = faces[None].expand(B, -1, -1)
+    ref = rend(Meshes(verts, fb, TexturesUV(m2.permute(0, 2, 3, 1), fb, uvs.expand(B, -1, -1))), sc["R"], sc["T"])
+    ref.backward(cot)
+    assert torch.equal(img, ref) and 0.03 < float(img[:, 3].detach().mean()) < 0.9
+    for a, b in ((disp, d2), (scales, s2), (maps, m2)):
+        assert rel_err(a.grad.cpu().numpy(), b.grad.cpu().numpy()) <= 2e-5
