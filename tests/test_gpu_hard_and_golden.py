@@ -71,6 +71,28 @@ def test_blend_colors_against_reference_golden(golden_dir, name):
     np.testing.assert_allclose(gds.cpu().numpy(), g["grad_dists"], atol=1e-5 * scale, rtol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["hard", "clip", "sigmoid"])
+def test_layered_rgb_blend_by_its_own_name_against_the_reference_golden(golden_dir, name):
+    """unicorn_amd.renderer.layered_rgb_blend(colors, fragments, blend_params, clip_inside, debug) -- the reference
+    function's name and signature (renderer.py:175-202) -- against that function's own outputs, autograd included"""
+    from unicorn_amd.renderer import BlendParams, Fragments, layered_rgb_blend
+    g = np.load(os.path.join(golden_dir, f"blend_{name}.npz"))
+    t = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    col, ds = t(g["colors"]).requires_grad_(True), t(g["dists"]).requires_grad_(True)
+    frags = Fragments(t(g["pix_to_face"], np.int32), torch.zeros_like(ds), torch.zeros(*ds.shape, 3, device="cuda"), ds)
+    bp = BlendParams(sigma=float(g["sigma"]), background_color=tuple(float(v) for v in g["background"]))
+    img = layered_rgb_blend(col, frags, bp, clip_inside=bool(g["clip_inside"]))
+    np.testing.assert_allclose(img.detach().cpu().numpy(), g["image"], atol=1e-5, rtol=0)
+    img.backward(t(g["cotangent"]))
+    np.testing.assert_allclose(col.grad.cpu().numpy(), g["grad_colors"], atol=1e-5, rtol=1e-4)
+    scale = max(1.0, float(np.abs(g["grad_dists"]).max()))
+    np.testing.assert_allclose(ds.grad.cpu().numpy(), g["grad_dists"], atol=1e-5 * scale, rtol=1e-4)
+    colors_bg, alpha, occ, image = layered_rgb_blend(col.detach(), frags, bp, clip_inside=bool(g["clip_inside"]), debug=True)
+    assert colors_bg.shape[-2] == col.shape[-2] + 1 and torch.equal(image, img.detach())
+    np.testing.assert_allclose(alpha.cpu().numpy(), g["debug_alpha"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(occ.cpu().numpy(), g["debug_occ_alpha"], atol=1e-6, rtol=0)
+
+
 def test_shade_blend_against_grid_sample_golden(golden_dir):
     """ur_shade_blend / _backward vs ATen grid_sample(flip(map), 2uv-1, bilinear, align_corners=True, 'border') as
     TexturesUV.sample_textures calls it (reached from renderer.py:162).  One opaque fragment per pixel (hard blend,

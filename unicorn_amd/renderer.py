@@ -276,6 +276,17 @@ class LayeredShader(nn.Module):
         return self.debug_outputs(colors, fragments, bp, image)
 
 
+def layered_rgb_blend(colors, fragments, blend_params, clip_inside=True, debug=False):
+    """The reference's blend function by its own name and signature (renderer.py:175-202): per-fragment colours
+    (N,H,W,K,3) composited front to back over the background -> (N,4,H,W); with `debug` the (colours + background layer,
+    alphas + trailing 1, transmittances, image) tuple of renderer.py:199-200.  One HIP kernel each way
+    (ur_blend_colors / ur_blend_colors_backward); gradients flow to `colors` and `fragments.dists`."""
+    shader = LayeredShader(blend_params=blend_params, clip_inside=clip_inside, shading_type='raw', debug=debug)
+    image = ops.blend_colors(colors, fragments.pix_to_face_i32, fragments.dists, None, shader.blend_mode(blend_params),
+                             blend_params.sigma, blend_params.gamma, _rgb3(blend_params.background_color))
+    return shader.debug_outputs(colors, fragments, blend_params, image) if debug else image
+
+
 def lit_colors(shading_type, meshes, fragments, lights, materials, R, T):
     """per-fragment colours (N,H,W,K,3) of LayeredShader's / SoftPhongShader's shading step"""
     if shading_type == 'gouraud':
