@@ -1,4 +1,5 @@
-"""dev helper (no GPU needed): the eager step's Python glue alone -- the two native wrappers replaced by stand-ins that
+"""(round-2 tool: its stand-ins have the round-2 signatures of the native wrappers)
+dev helper (no GPU needed): the eager step's Python glue alone -- the two native wrappers replaced by stand-ins that
 allocate what they would -- timed and profiled on CPU tensors."""
 import cProfile, os, pstats, sys, time
 import torch
