@@ -493,3 +493,15 @@ def test_meshes_built_the_reference_way_render_like_plain_tensors():
     assert torch.equal(img, ref) and 0.03 < float(img[:, 3].detach().mean()) < 0.9
     for a, b in ((disp, d2), (scales, s2), (maps, m2)):
         assert rel_err(a.grad.cpu().numpy(), b.grad.cpu().numpy()) <= 2e-5
+
+
+def test_empty_batch_renders_to_an_empty_image_tensor():
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesUV
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(1, level=1, tex_size=8, seed=0, device=dev)
+    fb, ub = sc["faces"][None].expand(1, -1, -1), sc["verts_uvs"][None].expand(1, -1, -1)
+    rend = Renderer((24, 40), faces_per_pixel=5, viz_size=(16, 16)).to(dev)
+    none = Meshes(sc["verts"][:0], fb[:0], TexturesUV(sc["maps"][:0], fb[:0], ub[:0]))
+    assert rend(none, sc["R"][:0], sc["T"][:0]).shape == (0, 4, 24, 40)
+    assert rend(none, sc["R"][:0], sc["T"][:0], viz_purpose=True).shape == (0, 4, 16, 16)

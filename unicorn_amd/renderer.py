@@ -344,6 +344,9 @@ class MeshRenderer(nn.Module):
 
     def forward(self, meshes, **kwargs):
         shader = self.shader  # (a sub-module: every `self.shader` goes through nn.Module.__getattr__)
+        if len(meshes) == 0:  # an empty batch (the last, ragged batch of a loader can be): nothing to launch
+            H, W = kwargs.get("raster_settings", self.rasterizer.raster_settings).image_size
+            return torch.zeros(0, 4, H, W, device=kwargs["R"].device)
         if self.fused and isinstance(shader, LayeredShader) and shader.shading_type == 'raw' \
                 and isinstance(meshes.textures, TexturesUV) and not shader.debug:
             return shader.render_fused(self.rasterizer, meshes, **kwargs)
