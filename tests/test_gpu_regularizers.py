@@ -58,3 +58,43 @@ def test_rejects_open_meshes():
     from unicorn_amd import regularizers
     with pytest.raises(ValueError):
         regularizers.build_topology(np.array([[0, 1, 2], [0, 2, 3]]))
+
+
+def test_the_reference_call_pattern_shares_one_launch():
+    """unicorn.py:259-266 + 340-343: template.extend(B) (the copies share the template's face table), offset_verts_,
+    then normal_consistency(meshes) and laplacian_smoothing(meshes) as two calls: the second is served from the first's
+    launch; the terms can be back-propagated together or one after the other; a changed vertex tensor is seen"""
+    from unicorn_amd import regularizers
+    from unicorn_amd.structures import Meshes
+    dev = "cuda:0"
+    v, f = synth.icosphere(2)
+    v, f = v.to(dev), f.to(dev)
+    B = 3
+    disp0 = 0.05 * torch.randn(B * v.shape[0], 3, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+
+    def batch(disp):
+        m = Meshes(v[None], f[None]).extend(B)
+        assert m.faces_padded().stride(0) == 0          # one table, not B copies
+        m.offset_verts_(disp)
+        return m
+    d1 = disp0.clone().requires_grad_(True)
+    m = batch(d1)
+    n1 = regularizers.normal_consistency(m)
+    l1 = regularizers.laplacian_smoothing(m, method="uniform")
+    assert n1.grad_fn is l1.grad_fn                     # both from ONE autograd node = one launch
+    (0.3 * n1 + 0.7 * l1).backward()
+    d2 = disp0.clone().requires_grad_(True)
+    n2, l2 = regularizers.mesh_regularizers(Meshes(v[None] + d2.view(B, -1, 3), f[None].expand(B, -1, -1)))
+    (0.3 * n2 + 0.7 * l2).backward()
+    assert float(n1.detach()) == float(n2.detach()) and float(l1.detach()) == float(l2.detach())
+    assert torch.equal(d1.grad, d2.grad)
+    # one after the other
+    d3 = disp0.clone().requires_grad_(True)
+    m3 = batch(d3)
+    (0.3 * regularizers.normal_consistency(m3)).backward()
+    (0.7 * regularizers.laplacian_smoothing(m3)).backward()
+    assert rel(d3.grad.cpu().numpy(), d1.grad.cpu().numpy()) < 1e-6
+    # new vertices on the same batch object: not served from the old launch
+    before = float(regularizers.normal_consistency(m3).detach())
+    m3.scale_verts_(torch.tensor([1.0, 2.0, 0.5], device=dev).expand(B, 3))
+    assert float(regularizers.normal_consistency(m3).detach()) != before

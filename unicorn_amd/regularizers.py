@@ -61,14 +61,14 @@ class _MeshReg(Function):
         need = verts.requires_grad
         nsum, lsum, gN, gL = native.mesh_regularizers(verts, quads, off, idx, need)
         N, V, E = verts.shape[0], verts.shape[1], quads.shape[0]
-        ctx.save_for_backward(gN, gL)
+        ctx.grads = (gN, gL)  # (plain attributes, not saved tensors: the two terms may be back-propagated one by one)
         ctx.scale = (1.0 / (N * E), 1.0 / (N * V))
         return nsum.sum() * ctx.scale[0], lsum.sum() * ctx.scale[1]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_normal, g_lap):
-        gN, gL = ctx.saved_tensors
+        gN, gL = ctx.grads
         return gN * (g_normal * ctx.scale[0]) + gL * (g_lap * ctx.scale[1]), None, None, None
 
 
@@ -82,8 +82,16 @@ def mesh_regularizers(meshes):
     faces = meshes.faces_padded()
     if faces.stride(0) != 0 and len(meshes) > 1 and not bool((faces == faces[:1]).all()):
         raise NotImplementedError("meshes must share one topology (utils/mesh.py:92 shared_topology=True)")
+    # unicorn.py:340-343 asks for the two terms in two calls on the same batch: the second is served from the first's
+    # launch (kept on the batch object for as long as its vertex tensor is the same, unmodified one)
+    verts = meshes.verts_padded()
+    kept = getattr(meshes, "_regularizer_terms", None)
+    if kept is not None and kept[0] is verts and kept[1] == verts._version and kept[2] == torch.is_grad_enabled():
+        return kept[3]
     quads, off, idx = _topology(faces[0])
-    return _MeshReg.apply(meshes.verts_padded(), quads, off, idx)
+    terms = _MeshReg.apply(verts, quads, off, idx)
+    meshes._regularizer_terms = (verts, verts._version, torch.is_grad_enabled(), terms)
+    return terms
 
 
 def normal_consistency(meshes, icosphere_topology=True, shared_topology=True):

@@ -405,7 +405,12 @@ class Meshes:
         """N copies of every mesh, repeat_interleave order (m0, m0, ..., m1, m1, ...)"""
         tex = self.textures.extend(N) if self.textures is not None else None
         if self._equisized and self._N:
-            return Meshes(self.verts_padded().repeat_interleave(N, 0), self.faces_padded().repeat_interleave(N, 0), tex)
+            faces = self.faces_padded()
+            # a single mesh (unicorn.py:263 extends its one template): the copies share its face table -- an expanded
+            # view, never written to -- so that the renderer's and the regularisers' shared-topology paths see ONE table
+            # (the vertices are copied: offset_verts_ / scale_verts_ replace them anyway)
+            faces = faces.expand(N, -1, -1) if self._N == 1 else faces.repeat_interleave(N, 0)
+            return Meshes(self.verts_padded().repeat_interleave(N, 0), faces, tex)
         verts, faces = [], []
         for v, f in zip(self.verts_list(), self.faces_list()):
             verts += [v.clone() for _ in range(N)]
