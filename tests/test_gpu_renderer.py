@@ -505,3 +505,51 @@ def test_empty_batch_renders_to_an_empty_image_tensor():
     none = Meshes(sc["verts"][:0], fb[:0], TexturesUV(sc["maps"][:0], fb[:0], ub[:0]))
     assert rend(none, sc["R"][:0], sc["T"][:0]).shape == (0, 4, 24, 40)
     assert rend(none, sc["R"][:0], sc["T"][:0], viz_purpose=True).shape == (0, 4, 16, 16)
+
+
+def test_neighbour_swap_batches_reuse_tables_and_textures_of_the_rendered_batch():
+    """unicorn.py:350,389,407: the neighbour loss takes verts_padded(), faces_padded() and .textures of the batch it has
+    just rendered, and builds two more batches from them - swapped shapes `Meshes((verts / scales) * sh_S, faces,
+    sh_tx)` and swapped textures `Meshes(tx_verts * tx_S, faces, textures)`.  Both render like batches built from plain
+    tensors, and the gradients reach the vertices and the texture maps of the first batch through the shared objects"""
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesUV
+    dev = torch.device("cuda:0")
+    B, H = 3, 40
+    sc = synth.make_scene(B, level=2, tex_size=16, seed=4, device=dev)
+    faces, uvs = sc["faces"], sc["verts_uvs"][None]
+    fb, ub = faces[None].expand(B, -1, -1), uvs.expand(B, -1, -1)
+    g = torch.Generator(device=dev).manual_seed(2)
+    tmpl = synth.icosphere(2)[0].to(dev) * 0.5
+    scales = (1.0 + 0.2 * torch.rand(B, 3, device=dev, generator=g))[:, None]
+    sh_S, tx_S = [(1.0 + 0.2 * torch.rand(B, 1, 3, device=dev, generator=g)) for _ in range(2)]
+    tx_verts = tmpl[None] + 0.03 * torch.randn(B, tmpl.shape[0], 3, device=dev, generator=g)
+    sh_maps = torch.rand(B, 16, 16, 3, device=dev, generator=g)
+    cots = [torch.randn(B, 4, H, H, device=dev, generator=g) for _ in range(3)]
+    rend = Renderer(H, cameras={"name": "fov", "fov": 30}, faces_per_pixel=10, sigma=1e-4).to(dev)
+
+    def run(shared):
+        disp = (0.03 * torch.ones(B * tmpl.shape[0], 3, device=dev)).requires_grad_(True)
+        maps = sc["maps"].clone().requires_grad_(True)
+        meshes = Meshes(tmpl[None], faces[None]).extend(B)
+        meshes.offset_verts_(disp)
+        meshes.textures = TexturesUV(maps, fb, ub)
+        meshes.scale_verts_(scales[:, 0])
+        if shared:
+            verts, f, textures = meshes.verts_padded(), meshes.faces_padded(), meshes.textures
+            sh_tx = TexturesUV(sh_maps, f, ub)
+        else:
+            verts = (tmpl[None] + disp.view(B, -1, 3)) * scales
+            f, textures, sh_tx = fb.contiguous(), TexturesUV(maps, fb.contiguous(), ub.contiguous()), TexturesUV(sh_maps, fb, ub)
+            meshes = Meshes(verts, f, textures)
+        batches = [meshes, Meshes((verts / scales) * sh_S, f, sh_tx), Meshes(tx_verts * tx_S, f, textures)]
+        imgs = [rend(m, sc["R"], sc["T"]) for m in batches]
+        sum((i * c).sum() for i, c in zip(imgs, cots)).backward()
+        return imgs, disp.grad, maps.grad
+    imgs_a, gd_a, gm_a = run(True)
+    imgs_b, gd_b, gm_b = run(False)
+    for a, b in zip(imgs_a, imgs_b):
+        assert torch.equal(a, b) and 0.03 < float(a[:, 3].detach().mean()) < 0.9
+    assert rel_err(gd_a.cpu().numpy(), gd_b.cpu().numpy()) <= 2e-5
+    assert rel_err(gm_a.cpu().numpy(), gm_b.cpu().numpy()) <= 2e-5
+    assert float(gm_a.abs().sum()) > 0 and float(gd_a.abs().sum()) > 0
