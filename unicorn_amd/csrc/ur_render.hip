@@ -1478,13 +1478,23 @@ __global__ void __launch_bounds__(G8 ? 512 : 256, UR_RASTER_WPS) k_raster(const 
       // owners composite their items of this round, in depth order, and leave the transmittance in front of each
       const int s0 = max(pre, base), e0 = min(pre + m, base + 64 * U);
       const int nloop = __builtin_amdgcn_readfirstlane(wave_max(max(e0 - s0, 0)));
-      for (int t = 0; t < nloop; ++t) {
-        if (s0 + t < e0) {
-          const float4 c = s_res[s0 + t - base];
-          s_occ[s0 + t - base] = occ;
-          r += occ * c.x * c.y; g += occ * c.x * c.z; b += occ * c.x * c.w;
-          occ = occ * (1.0f - c.x);
-        }
+      // (four steps per trip, their LDS reads issued together: the deepest pixel of the round sets the trip count, up
+      // to K, and every step used to wait for its own read; composite time of the last waves 4.4 -> 3.6 us, the
+      // kernel -0.5 us at the headline size.  The arithmetic and its order are unchanged.)
+#ifndef UR_COMP_UNROLL
+#define UR_COMP_UNROLL 4
+#endif
+      for (int t = 0; t < nloop; t += UR_COMP_UNROLL) {
+        float4 c[UR_COMP_UNROLL];
+#pragma unroll
+        for (int i = 0; i < UR_COMP_UNROLL; ++i) c[i] = s_res[min(max(s0 + t + i - base, 0), 64 * U - 1)];
+#pragma unroll
+        for (int i = 0; i < UR_COMP_UNROLL; ++i)
+          if (s0 + t + i < e0) {
+            s_occ[s0 + t + i - base] = occ;
+            r += occ * c[i].x * c[i].y; g += occ * c[i].x * c[i].z; b += occ * c[i].x * c[i].w;
+            occ = occ * (1.0f - c[i].x);
+          }
       }
       // the layer rows for the backward, written by the lanes that computed them: 64 consecutive 32-byte rows per
       // store instruction
