@@ -1,5 +1,5 @@
 """dev helper: the stage stamps inside the fused tail's shading rounds, from a dump written by tools/fwd_phase_times.py
-(UR_DEV_DUMP=...) run on a build with those stamps (the replacement list is in profiles/r03_fwd_balance.txt's last block:
+(UR_DEV_DUMP=...) run on a build with those stamps (tools/mk_fwd_tail_timing.sh:
 slots 6, 7, 9, 12, 13 of a wave's record = marks + keys, face load + eval, texels, composite, row stores).
 usage: fwd_tail_stages.py dump.pt"""
 import sys, torch
