@@ -95,8 +95,16 @@ def redeal(order, cost, live):
 
 img0, order0, wg0, span0, fwd0 = stamped(None)
 print(f"library schedule: k_raster<2> span {span0:.1f} us (timing build), whole forward {fwd0:.1f} us")
+def by_cost(order, cost, live):
+    """plain longest-first order (what a launch of several rounds wants: every freed slot takes the next-longest bin)"""
+    pos = sorted((i for i in range(nblk) if live[i]), key=lambda i: -float(cost[i]))
+    new = [int(order[i]) for i in pos] + [int(order[i]) for i in range(nblk) if not live[i]]
+    return torch.tensor(new, dtype=torch.int32, device=dev)
+
+
+LPT = os.environ.get("UR_DEV_ORACLE_MODE", "cu") == "lpt"
 for name in ("dur", "pairs", "rows"):
-    new = redeal(order0, wg0[name], wg0["live"])
+    new = by_cost(order0, wg0[name], wg0["live"]) if LPT else redeal(order0, wg0[name], wg0["live"])
     img1, _, wg1, span1, fwd1 = stamped(new)
     assert torch.equal(img0, img1), "the schedule changed the picture"
-    print(f"bins re-dealt over the CUs by run 1's {name:5s}: span {span1:.1f} us, whole forward {fwd1:.1f} us")
+    print(f"bins {'in longest-first order of' if LPT else 're-dealt over the CUs by'} run 1's {name:5s}: span {span1:.1f} us, whole forward {fwd1:.1f} us")
