@@ -553,3 +553,48 @@ def test_neighbour_swap_batches_reuse_tables_and_textures_of_the_rendered_batch(
     assert rel_err(gd_a.cpu().numpy(), gd_b.cpu().numpy()) <= 2e-5
     assert rel_err(gm_a.cpu().numpy(), gm_b.cpu().numpy()) <= 2e-5
     assert float(gm_a.abs().sum()) > 0 and float(gd_a.abs().sum()) > 0
+
+
+def test_duplicate_faces_and_a_mesh_behind_the_camera():
+    """exact depth ties through the fused path (three copies of a face: the smaller face index comes first, SURVEY 8a
+    spec block) and a mesh that lies wholly behind the camera (background only, zero gradients)"""
+    from unicorn_amd.renderer import Renderer
+    from unicorn_amd.structures import Meshes, TexturesUV
+    N, F, K, H = 2, 40, 6, 40
+    sc = _soup(N, F, seed=11, behind=False)
+    v = sc["verts"].view(N, F, 3, 3)
+    v[0, 6] = v[0, 5]
+    v[0, 7] = v[0, 5]
+    v[0, 5:8, :, :2] *= 0.0
+    v[0, 5:8, :, :2] += torch.tensor([[-0.3, -0.3], [0.35, -0.25], [0.0, 0.4]])      # a large face in view, three times over
+    v[0, 5:8, :, 2] = 2.0
+    v[1, :, :, 2] = -v[1, :, :, 2].abs() - 0.5                                        # mesh 1: everything behind the camera
+    dev = torch.device("cuda:0")
+    rend = Renderer(H, cameras={"name": "fov", "fov": 30}, faces_per_pixel=K, sigma=1e-4).to(dev)
+    verts = sc["verts"].to(dev).requires_grad_(True)
+    maps = sc["maps"].to(dev).requires_grad_(True)
+    R, T = sc["R"].to(dev).requires_grad_(True), sc["T"].to(dev).requires_grad_(True)
+    fb = sc["faces"].to(dev)[None].expand(N, -1, -1)
+    ub = sc["verts_uvs"].to(dev)[None].expand(N, -1, -1)
+    cot = np.random.RandomState(5).randn(N, 4, H, H).astype(np.float32)
+    ref, (gv, gR, gT, gm) = _oracle(sc, H, H, K, S30, 1e-4, cot)
+    meshes = Meshes(verts=verts, faces=fb, textures=TexturesUV(maps, fb, ub))
+    out = rend(meshes, R, T)
+    out.backward(torch.tensor(cot, device=dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=1e-5, rtol=0)
+    assert torch.equal(out[1, :3].detach(), torch.ones_like(out[1, :3])) and float(out[1, 3].detach().abs().max()) == 0.0
+    assert float(verts.grad[1].abs().max()) == 0.0 and float(maps.grad[1].abs().max()) == 0.0
+    assert float(R.grad[1].abs().max()) == 0.0 and float(T.grad[1].abs().max()) == 0.0
+
+    def oracle64():
+        g = _oracle(sc, H, H, K, S30, 1e-4, cot, dtype=np.float64)[1]
+        return dict(verts=g[0], R=g[1], T=g[2], maps=g[3])
+    assert_grads_to_the_bar({k: t.grad.cpu().numpy() for k, t in (("verts", verts), ("maps", maps), ("R", R), ("T", T))},
+                            dict(verts=gv, R=gR, T=gT, maps=gm), oracle64, "duplicates")
+    # the fragments of the same scene: the three copies occupy consecutive layers in face-index order wherever they show
+    frag = rend.renderer.rasterizer(meshes, R=R, T=T)
+    p2f = frag.pix_to_face[0].cpu().numpy()
+    where5 = np.argwhere(p2f == 5)
+    assert len(where5) > 50
+    for y, x, k in where5[:200]:
+        assert k + 2 < K and p2f[y, x, k + 1] == 6 and p2f[y, x, k + 2] == 7
